@@ -1,0 +1,190 @@
+/*
+ * rt_hip.h - C ABI of the MI355X (gfx950) Whitted tracer.
+ *
+ * The library replaces ONE call of the reference renderer: the free function
+ *   void Tracer(const Color& bgr, Screen& scr, objs, lights)      (src/main.cc:115-141)
+ * together with everything it reaches per pixel (TraceRay src/main.cc:19-113,
+ * Object::Shade src/objects.h:20-65, Plane/Sphere::TestCollision/calcNormal
+ * src/objects.h:91-106,124-142, ViewFrustum src/view_frustum.h:20-47,
+ * Screen::StorePixel src/screen.h:55-73, Color::red/green/blue src/color.h:27-29).
+ *
+ * The reference has no FFI of its own; these entry points are what a binding for that
+ * call would need.  Everything crossing the boundary is a plain pointer, a size or a POD
+ * struct of doubles/int32.  All host buffers are owned by the caller, all device memory
+ * by the library.  Calls block unless stated otherwise.  A context belongs to one
+ * device and must not be used from two threads at once.
+ *
+ * Every function returning int returns RT_OK (0) or a negative RT_ERR_* code; the text
+ * of the last failure is available from rt_last_error().
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------------------ */
+#define RT_OK 0
+#define RT_ERR_ARG (-1)      /* bad argument (null pointer, size out of range, ...)      */
+#define RT_ERR_HIP (-2)      /* a HIP runtime call failed (no device, launch failure...) */
+#define RT_ERR_STATE (-3)    /* call order wrong (render before upload, ...)             */
+#define RT_ERR_NOMEM (-4)    /* host or device allocation failed                          */
+
+/* ---- limits ------------------------------------------------------------------------ */
+#define RT_MAX_DEPTH 8       /* largest max_depth: node masks are 2^(max_depth-1) bits   */
+#define RT_MAX_PRIMS 65536
+#define RT_MAX_LIGHTS 256
+
+#define RT_PRIM_PLANE 0
+#define RT_PRIM_SPHERE 1
+
+/*
+ * One collider, flattened from the reference's Plane / Sphere objects
+ * (src/objects.h:82-111, 114-147) plus the DiffuseMaterial (src/color.h:66-74) and the
+ * ambient Light (src/common.h:47-54) every Object carries (src/objects.h:77-78).
+ * Order in the array = order in the reference's `colliders` vector; it decides ties in
+ * the nearest-hit loop (src/main.cc:39-47) and which occluder a shadow feeler sees first
+ * (src/objects.h:35-47).
+ */
+typedef struct rt_prim {
+    int32_t type;             /* RT_PRIM_PLANE | RT_PRIM_SPHERE                           */
+    int32_t reserved;         /* must be 0                                               */
+    double p[3];              /* plane: origin_ ; sphere: center_                        */
+    double q[3];              /* plane: normal_ AS STORED, i.e. after the constructor's
+                                 makeNormal (src/objects.h:88); sphere: {radius_, 0, 0},
+                                 radius_ already widened from the constructor's float
+                                 (src/objects.h:116,146)                                 */
+    double kd[3];             /* material().kd r,g,b (ka and ks are never read)          */
+    double reflectivity;      /* src/color.h:71                                          */
+    double transparency;      /* src/color.h:72                                          */
+    double refraction_index;  /* src/color.h:73                                          */
+    double ambient_intensity; /* double(GetAmbient().intensity), a float in the reference
+                                 (src/common.h:53, used at src/main.cc:112)              */
+} rt_prim;
+
+/* One PointLight (src/common.h:57-64). intensity = double(float intensity). */
+typedef struct rt_light {
+    double pos[3];
+    double color[3];          /* light_color r,g,b                                       */
+    double intensity;
+} rt_light;
+
+/* rt_params.flags */
+#define RT_FLAG_COUNTERS 1u   /* also count events into rt_counters (slower kernel)      */
+
+/*
+ * Per-render parameters: the values the reference hard-wires in Tracer()/main()
+ * (frame size src/main.cc:215, FOV 60 src/main.cc:126, MAX_DEPTH src/main.cc:17,
+ * background src/main.cc:221) made runtime, plus the row partition used to split one
+ * frame across GPUs.
+ *
+ * Row partition: the frame is cut into bands of `band_rows` consecutive image rows,
+ * band b covering rows [b*band_rows, (b+1)*band_rows).  A render produces bands
+ * band_first, band_first+band_step, ... (band_count of them), packed one after the
+ * other in the output buffers ("strip order").  A band that sticks out of the frame is
+ * clipped; rt_strip_rows() gives the number of rows a partition really holds.
+ * The whole frame is band_rows=height, band_first=0, band_step=1, band_count=1.
+ */
+typedef struct rt_params {
+    int32_t width, height;    /* frame size in pixels                                    */
+    int32_t max_depth;        /* reference MAX_DEPTH: a ray at depth >= max_depth returns
+                                 the background untraced; 2..RT_MAX_DEPTH                */
+    int32_t band_rows, band_first, band_step, band_count;
+    uint32_t flags;
+    double fov_deg;           /* horizontal field of view in degrees (reference: 60)     */
+    double bgr[3];            /* background colour r,g,b (reference: .58,.76,.92)        */
+} rt_params;
+
+/*
+ * Event counts over one render (only filled when RT_FLAG_COUNTERS is set).
+ * rays = TraceRay invocations that pass the depth stop (src/main.cc:31-34), i.e. the sum
+ * of the spawn-mask popcounts; it is the ray count behind every Mrays/s figure.
+ */
+typedef struct rt_counters {
+    uint64_t rays;            /* traced rays, primary + secondary                        */
+    uint64_t primary_hits;    /* depth-1 rays that found an object                       */
+    uint64_t hits;            /* rays that found an object, all depths                   */
+    uint64_t sphere_tests;    /* Sphere::TestCollision calls, tracing + feelers          */
+    uint64_t plane_tests;     /* Plane::TestCollision calls, tracing + feelers           */
+    uint64_t feelers;         /* (hit, light) pairs shaded                               */
+    uint64_t feelers_occluded;/* feelers that met an occluder                            */
+    uint64_t refractions;     /* refraction children spawned (k > 0, src/main.cc:87)     */
+} rt_counters;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Number of 32-bit words of one pixel's hit/spawn mask: max(1, 2^(max_depth-1) / 32).   */
+int32_t rt_mask_words(int32_t max_depth);
+
+/* Rows held by the partition in `p` (after clipping to the frame), or RT_ERR_ARG.       */
+int32_t rt_strip_rows(const rt_params* p);
+
+/* Library version, "major.minor".                                                       */
+const char* rt_version(void);
+
+/* Create a context on HIP device `device_id`.  Fails with RT_ERR_HIP when no gfx950
+ * device (or no device at all) is usable: there is no CPU fallback.                     */
+int rt_create(int32_t device_id, rt_ctx** out);
+void rt_destroy(rt_ctx* ctx);
+
+/* Last error text of `ctx` (or of rt_create when ctx is NULL).  Never NULL.             */
+const char* rt_last_error(const rt_ctx* ctx);
+
+/*
+ * Copy the scene to the device.  Replaces the `objs` / `lights` arguments of Tracer()
+ * (src/main.cc:118-119).  1 <= n_prims <= RT_MAX_PRIMS, 0 <= n_lights <= RT_MAX_LIGHTS.
+ */
+int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims,
+                    const rt_light* lights, int32_t n_lights);
+
+/*
+ * Render the partition described by `p` into HOST buffers, strip order, row 0 of a band
+ * first, x ascending; image row 0 is the BOTTOM scanline as in the reference's
+ * framebuffer (src/screen.h:62-64, bottom-up DIB src/screen.h:102-112).
+ *   bgr        rows*width*3 bytes, B,G,R per pixel (src/screen.h:62-64)       required
+ *   hit_id     rows*width int32: index of the object the primary ray hit
+ *              (current_obj at src/main.cc:44, depth 1), -1 on a miss         nullable
+ *   hit_mask   rows*width*rt_mask_words(max_depth) uint32. Nodes of the ray tree are
+ *              heap-numbered: root 1, reflection child of i = 2i (src/main.cc:80),
+ *              refraction child = 2i+1 (src/main.cc:94). Bit i (word i/32, bit i%32)
+ *              is set iff node i was traced and found an object               nullable
+ *   spawn_mask same shape: bit i set iff TraceRay was entered for node i with
+ *              depth < max_depth                                              nullable
+ *   counters   filled when RT_FLAG_COUNTERS is set                            nullable
+ * Replaces Tracer() + Screen::StorePixel for the rows of the partition.
+ */
+int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id,
+              uint32_t* hit_mask, uint32_t* spawn_mask, rt_counters* counters);
+
+/*
+ * Same render, but every output pointer is DEVICE memory on the context's device and
+ * the work is only enqueued on `stream` (a hipStream_t, NULL = the default stream); the
+ * call returns without waiting.  d_counters (device, nullable) must be zeroed by the
+ * caller; counts are ADDED to it.  This is the form used under a collective: the strip
+ * is rendered straight into the buffer RCCL sends.
+ */
+int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_bgr,
+                     int32_t* d_hit_id, uint32_t* d_hit_mask, uint32_t* d_spawn_mask,
+                     rt_counters* d_counters);
+
+/*
+ * Test hooks: run the device versions of the reference's collision tests and of the
+ * vector normalisation on caller-supplied rays, so that their double results can be
+ * compared bit for bit with a CPU evaluation.
+ *   rays      n * 6 doubles on the host: origin xyz, direction xyz (used as given)
+ *   prim      index into the uploaded scene
+ *   t_out     n doubles: the collision parameter (src/objects.h:91-102,124-138)
+ *   hit_out   n bytes: 1 = TestCollision returned a value, 0 = nullopt
+ *   unit_out  n * 3 doubles: normalize(direction) as gmtl does it (length, then three
+ *             divisions; unchanged when the length is 0)                      nullable
+ */
+int rt_debug_intersect(rt_ctx* ctx, const double* rays, int32_t n, int32_t prim,
+                       double* t_out, uint8_t* hit_out, double* unit_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */
