@@ -1,0 +1,319 @@
+// C ABI of the tracer (include/rt_hip.h): context, scene upload, render, test hooks.
+// Host code only; the kernels live in whitted_kernels.hip.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "whitted_device.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    std::string err;
+    rt::DGeom* d_geom = nullptr;
+    rt::DMat* d_mat = nullptr;
+    rt::DLight* d_lights = nullptr;
+    int32_t n_prims = 0, n_lights = 0;
+    bool have_scene = false;
+    // grow-only device staging for rt_render's host outputs
+    DevBuf bgr, hit_id, hit_mask, spawn_mask, counters, dbg_in, dbg_t, dbg_hit, dbg_unit;
+    hipStream_t stream = nullptr;
+};
+
+namespace {
+
+int fail(rt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+int hip_fail(rt_ctx* ctx, hipError_t e, const char* what) {
+    std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+    int code = (e == hipErrorOutOfMemory) ? RT_ERR_NOMEM : RT_ERR_HIP;
+    return fail(ctx, code, msg);
+}
+
+#define RT_HIP_TRY(ctx, call)                                 \
+    do {                                                      \
+        hipError_t e__ = (call);                              \
+        if (e__ != hipSuccess) return hip_fail(ctx, e__, #call); \
+    } while (0)
+
+int reserve(rt_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return RT_OK;
+    if (b.ptr) RT_HIP_TRY(ctx, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.cap = 0;
+    RT_HIP_TRY(ctx, hipMalloc(&b.ptr, bytes));
+    b.cap = bytes;
+    return RT_OK;
+}
+
+int check_params(const rt_params* p) {
+    if (!p) return RT_ERR_ARG;
+    if (p->width < 1 || p->height < 1 || p->width > 65536 || p->height > 65536) return RT_ERR_ARG;
+    if (p->max_depth < 2 || p->max_depth > RT_MAX_DEPTH) return RT_ERR_ARG;
+    if (p->band_rows < 1 || p->band_first < 0 || p->band_step < 1 || p->band_count < 0) return RT_ERR_ARG;
+    if (!(p->fov_deg > 0.0 && p->fov_deg < 180.0)) return RT_ERR_ARG;
+    return RT_OK;
+}
+
+// Fill the kernel arguments for the partition in p.  The camera arithmetic is the
+// ViewFrustum constructor's (src/view_frustum.h:18,28-34), evaluated on the host in
+// double exactly as written there.
+int make_args(rt_ctx* ctx, const rt_params* p, rt::KArgs& a) {
+    if (check_params(p) != RT_OK) return fail(ctx, RT_ERR_ARG, "rt_params: value out of range");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    std::memset(&a, 0, sizeof a);
+    a.geom = ctx->d_geom;
+    a.mat = ctx->d_mat;
+    a.lights = ctx->d_lights;
+    a.n_prims = ctx->n_prims;
+    a.n_lights = ctx->n_lights;
+    a.width = p->width;
+    a.height = p->height;
+    a.max_depth = p->max_depth;
+    a.band_rows = p->band_rows;
+    a.band_first = p->band_first;
+    a.band_step = p->band_step;
+    a.rows = rt_strip_rows(p);
+    a.tiles_x = (a.width + rt::kTile - 1) / rt::kTile;
+    a.tiles_y = (a.rows + rt::kTile - 1) / rt::kTile;
+    a.mask_words = rt_mask_words(p->max_depth);
+
+    const double TO_RAD = 3.141592653589793 / 180.;
+    const double aspect = static_cast<double>(p->height) / static_cast<double>(p->width);
+    const double phy_width = 2 * 1 * std::tan(0.5 * p->fov_deg * TO_RAD);
+    const double phy_height = aspect * phy_width;
+    a.pw = phy_width / p->width;
+    a.ph = phy_height / p->height;
+    for (int i = 0; i < 3; ++i) a.bgr_c[i] = p->bgr[i];
+    for (int dpt = 1; dpt <= RT_MAX_DEPTH; ++dpt) a.inv_depth[dpt] = 1.0 / dpt;  // src/main.cc:112
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t rt_mask_words(int32_t max_depth) {
+    if (max_depth < 1 || max_depth > RT_MAX_DEPTH) return RT_ERR_ARG;
+    const int bits = 1 << (max_depth - 1);
+    return bits < 32 ? 1 : bits / 32;
+}
+
+int32_t rt_strip_rows(const rt_params* p) {
+    if (check_params(p) != RT_OK) return RT_ERR_ARG;
+    int64_t rows = 0;
+    for (int b = 0; b < p->band_count; ++b) {
+        const int64_t y0 = (static_cast<int64_t>(p->band_first) + static_cast<int64_t>(b) * p->band_step) * p->band_rows;
+        if (y0 >= p->height) break;
+        int64_t y1 = y0 + p->band_rows;
+        if (y1 > p->height) y1 = p->height;
+        rows += y1 - y0;
+    }
+    return static_cast<int32_t>(rows);
+}
+
+const char* rt_version(void) { return "0.1"; }
+
+int rt_create(int32_t device_id, rt_ctx** out) {
+    if (!out) return fail(nullptr, RT_ERR_ARG, "rt_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, RT_ERR_HIP, std::string("rt_create: no HIP device: ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count) return fail(nullptr, RT_ERR_ARG, "rt_create: device id out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, RT_ERR_HIP, std::string("rt_create: device is ") + prop.gcnArchName +
+                                             ", this library holds gfx950 code only");
+    rt_ctx* ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return fail(nullptr, RT_ERR_NOMEM, "rt_create: out of host memory");
+    ctx->device = device_id;
+    e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return hip_fail(nullptr, e, "rt_create: stream");
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    DevBuf* bufs[] = {&ctx->bgr, &ctx->hit_id, &ctx->hit_mask, &ctx->spawn_mask, &ctx->counters,
+                      &ctx->dbg_in, &ctx->dbg_t, &ctx->dbg_hit, &ctx->dbg_unit};
+    for (DevBuf* b : bufs)
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (ctx->d_geom) (void)hipFree(ctx->d_geom);
+    if (ctx->d_mat) (void)hipFree(ctx->d_mat);
+    if (ctx->d_lights) (void)hipFree(ctx->d_lights);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt_light* lights, int32_t n_lights) {
+    if (!ctx) return RT_ERR_ARG;
+    if (!prims || n_prims < 1 || n_prims > RT_MAX_PRIMS) return fail(ctx, RT_ERR_ARG, "rt_upload_scene: n_prims");
+    if (n_lights < 0 || n_lights > RT_MAX_LIGHTS || (n_lights > 0 && !lights))
+        return fail(ctx, RT_ERR_ARG, "rt_upload_scene: n_lights");
+    std::vector<rt::DGeom> geom(n_prims);
+    std::vector<rt::DMat> mat(n_prims);
+    std::vector<rt::DLight> lt(n_lights > 0 ? n_lights : 1);
+    for (int i = 0; i < n_prims; ++i) {
+        const rt_prim& s = prims[i];
+        if (s.type != RT_PRIM_PLANE && s.type != RT_PRIM_SPHERE)
+            return fail(ctx, RT_ERR_ARG, "rt_upload_scene: unknown primitive type");
+        rt::DGeom& g = geom[i];
+        rt::DMat& m = mat[i];
+        std::memset(&g, 0, sizeof g);
+        std::memset(&m, 0, sizeof m);
+        for (int c = 0; c < 3; ++c) {
+            g.p[c] = s.p[c];
+            g.q[c] = s.q[c];
+            m.kd[c] = s.kd[c];
+        }
+        // std::pow(radius_, 2) (src/objects.h:125) is radius_*radius_ correctly rounded.
+        g.r2 = (s.type == RT_PRIM_PLANE) ? -1.0 : s.q[0] * s.q[0];
+        g.transparency = s.transparency;
+        m.reflectivity = s.reflectivity;
+        m.transparency = s.transparency;
+        m.refraction_index = s.refraction_index;
+        m.ambient_intensity = s.ambient_intensity;
+    }
+    for (int i = 0; i < n_lights; ++i) {
+        std::memset(&lt[i], 0, sizeof lt[i]);
+        for (int c = 0; c < 3; ++c) {
+            lt[i].pos[c] = lights[i].pos[c];
+            lt[i].ci[c] = lights[i].color[c] * lights[i].intensity;  // src/objects.h:54-56
+        }
+    }
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->have_scene = false;
+    if (ctx->d_geom) RT_HIP_TRY(ctx, hipFree(ctx->d_geom));
+    if (ctx->d_mat) RT_HIP_TRY(ctx, hipFree(ctx->d_mat));
+    if (ctx->d_lights) RT_HIP_TRY(ctx, hipFree(ctx->d_lights));
+    ctx->d_geom = nullptr; ctx->d_mat = nullptr; ctx->d_lights = nullptr;
+    RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_geom), geom.size() * sizeof(rt::DGeom)));
+    RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_mat), mat.size() * sizeof(rt::DMat)));
+    RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_lights), lt.size() * sizeof(rt::DLight)));
+    RT_HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), geom.size() * sizeof(rt::DGeom), hipMemcpyHostToDevice));
+    RT_HIP_TRY(ctx, hipMemcpy(ctx->d_mat, mat.data(), mat.size() * sizeof(rt::DMat), hipMemcpyHostToDevice));
+    RT_HIP_TRY(ctx, hipMemcpy(ctx->d_lights, lt.data(), lt.size() * sizeof(rt::DLight), hipMemcpyHostToDevice));
+    ctx->n_prims = n_prims;
+    ctx->n_lights = n_lights;
+    ctx->have_scene = true;
+    return RT_OK;
+}
+
+int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_bgr, int32_t* d_hit_id,
+                     uint32_t* d_hit_mask, uint32_t* d_spawn_mask, rt_counters* d_counters) {
+    if (!ctx) return RT_ERR_ARG;
+    if (!d_bgr) return fail(ctx, RT_ERR_ARG, "rt_render_device: d_bgr is null");
+    rt::KArgs a;
+    int rc = make_args(ctx, p, a);
+    if (rc != RT_OK) return rc;
+    const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
+    if (count && !d_counters) return fail(ctx, RT_ERR_ARG, "RT_FLAG_COUNTERS set but counters is null");
+    a.bgr = d_bgr;
+    a.hit_id = d_hit_id;
+    a.hit_mask = d_hit_mask;
+    a.spawn_mask = d_spawn_mask;
+    a.counters = reinterpret_cast<unsigned long long*>(d_counters);
+    const bool emit = d_hit_id || d_hit_mask || d_spawn_mask;
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, static_cast<hipStream_t>(stream)));
+    return RT_OK;
+}
+
+int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id, uint32_t* hit_mask,
+              uint32_t* spawn_mask, rt_counters* counters) {
+    if (!ctx) return RT_ERR_ARG;
+    if (!bgr) return fail(ctx, RT_ERR_ARG, "rt_render: bgr is null");
+    if (check_params(p) != RT_OK) return fail(ctx, RT_ERR_ARG, "rt_params: value out of range");
+    const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
+    if (count && !counters) return fail(ctx, RT_ERR_ARG, "RT_FLAG_COUNTERS set but counters is null");
+    const size_t px = static_cast<size_t>(rt_strip_rows(p)) * p->width;
+    const size_t words = rt_mask_words(p->max_depth);
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = reserve(ctx, ctx->bgr, px * 3 + 4)) != RT_OK) return rc;
+    if (hit_id && (rc = reserve(ctx, ctx->hit_id, px * 4 + 4)) != RT_OK) return rc;
+    if (hit_mask && (rc = reserve(ctx, ctx->hit_mask, px * words * 4 + 4)) != RT_OK) return rc;
+    if (spawn_mask && (rc = reserve(ctx, ctx->spawn_mask, px * words * 4 + 4)) != RT_OK) return rc;
+    if (count) {
+        if ((rc = reserve(ctx, ctx->counters, sizeof(rt_counters))) != RT_OK) return rc;
+        RT_HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, sizeof(rt_counters), ctx->stream));
+    }
+    rc = rt_render_device(ctx, p, ctx->stream, static_cast<uint8_t*>(ctx->bgr.ptr),
+                          hit_id ? static_cast<int32_t*>(ctx->hit_id.ptr) : nullptr,
+                          hit_mask ? static_cast<uint32_t*>(ctx->hit_mask.ptr) : nullptr,
+                          spawn_mask ? static_cast<uint32_t*>(ctx->spawn_mask.ptr) : nullptr,
+                          count ? static_cast<rt_counters*>(ctx->counters.ptr) : nullptr);
+    if (rc != RT_OK) return rc;
+    if (px) {
+        RT_HIP_TRY(ctx, hipMemcpyAsync(bgr, ctx->bgr.ptr, px * 3, hipMemcpyDeviceToHost, ctx->stream));
+        if (hit_id) RT_HIP_TRY(ctx, hipMemcpyAsync(hit_id, ctx->hit_id.ptr, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (hit_mask)
+            RT_HIP_TRY(ctx, hipMemcpyAsync(hit_mask, ctx->hit_mask.ptr, px * words * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (spawn_mask)
+            RT_HIP_TRY(ctx, hipMemcpyAsync(spawn_mask, ctx->spawn_mask.ptr, px * words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (count)
+        RT_HIP_TRY(ctx, hipMemcpyAsync(counters, ctx->counters.ptr, sizeof(rt_counters), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_debug_intersect(rt_ctx* ctx, const double* rays, int32_t n, int32_t prim, double* t_out, uint8_t* hit_out,
+                       double* unit_out) {
+    if (!ctx) return RT_ERR_ARG;
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    if (!rays || n < 0 || !t_out || !hit_out || prim < 0 || prim >= ctx->n_prims)
+        return fail(ctx, RT_ERR_ARG, "rt_debug_intersect: bad argument");
+    if (n == 0) return RT_OK;
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t N = static_cast<size_t>(n);
+    if ((rc = reserve(ctx, ctx->dbg_in, N * 48)) != RT_OK) return rc;
+    if ((rc = reserve(ctx, ctx->dbg_t, N * 8)) != RT_OK) return rc;
+    if ((rc = reserve(ctx, ctx->dbg_hit, N)) != RT_OK) return rc;
+    if (unit_out && (rc = reserve(ctx, ctx->dbg_unit, N * 24)) != RT_OK) return rc;
+    RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->dbg_in.ptr, rays, N * 48, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP_TRY(ctx, rt::launch_debug_intersect(ctx->d_geom, prim, static_cast<const double*>(ctx->dbg_in.ptr), n,
+                                               static_cast<double*>(ctx->dbg_t.ptr),
+                                               static_cast<uint8_t*>(ctx->dbg_hit.ptr),
+                                               unit_out ? static_cast<double*>(ctx->dbg_unit.ptr) : nullptr,
+                                               ctx->stream));
+    RT_HIP_TRY(ctx, hipMemcpyAsync(t_out, ctx->dbg_t.ptr, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP_TRY(ctx, hipMemcpyAsync(hit_out, ctx->dbg_hit.ptr, N, hipMemcpyDeviceToHost, ctx->stream));
+    if (unit_out)
+        RT_HIP_TRY(ctx, hipMemcpyAsync(unit_out, ctx->dbg_unit.ptr, N * 24, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// Device-side data layout and launch interface of the Whitted kernels (gfx950 only).
+//
+// Scene records are 64 bytes so that one record is one s_load_dwordx16: inside the
+// object loops the record index is wave-uniform, the record lives in SGPRs and every
+// lane tests its own ray against the broadcast primitive.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_hip.h"
+
+namespace rt {
+
+// Geometry of one collider + the one material value a shadow feeler needs.
+// r2 < 0 marks a plane (q = unit normal as stored by the Plane constructor);
+// otherwise a sphere with r2 = radius*radius (std::pow(radius_,2), src/objects.h:125).
+struct DGeom {
+    double p[3];
+    double q[3];
+    double r2;
+    double transparency;
+};
+
+// Material of one collider, gathered per lane once per hit.
+struct DMat {
+    double kd[3];
+    double reflectivity;
+    double transparency;
+    double refraction_index;
+    double ambient_intensity;
+    double pad;
+};
+
+// One point light; ci = light_color * double(intensity) (src/objects.h:54-56).
+struct DLight {
+    double pos[3];
+    double ci[3];
+    double pad[2];
+};
+
+static_assert(sizeof(DGeom) == 64 && sizeof(DMat) == 64 && sizeof(DLight) == 64, "record size");
+
+// Per-lane stack entry in LDS: origin xyz, direction xyz, weight, node number.
+constexpr int kStackFields = 8;
+constexpr int kWavesPerBlock = 4;
+constexpr int kTile = 8;  // a wave renders an 8x8 pixel tile
+
+struct KArgs {
+    const DGeom* geom;
+    const DMat* mat;
+    const DLight* lights;
+    uint8_t* bgr;
+    int32_t* hit_id;
+    uint32_t* hit_mask;
+    uint32_t* spawn_mask;
+    unsigned long long* counters;  // 8 x u64, same order as rt_counters
+    int32_t n_prims, n_lights;
+    int32_t width, height, max_depth;
+    int32_t band_rows, band_first, band_step;
+    int32_t rows;              // rows of the strip after clipping
+    int32_t tiles_x, tiles_y;  // 8x8 tiles covering width x rows
+    int32_t mask_words;
+    double pw, ph;             // pixel pitch (src/view_frustum.h:33-34)
+    double bgr_c[3];
+    double inv_depth[RT_MAX_DEPTH + 1];  // 1.0/depth for depth 1..max_depth-1
+};
+
+// Bytes of dynamic LDS one block needs for a given max_depth.
+inline size_t stack_lds_bytes(int max_depth) {
+    int entries = max_depth - 2;
+    if (entries < 1) entries = 1;
+    return (size_t)kWavesPerBlock * entries * kStackFields * 64 * sizeof(double);
+}
+
+// Enqueue the render of one strip on `stream`.  emit = write hit_id/masks (pointers in
+// `a` that are null are skipped), count = add event counts to a.counters.
+hipError_t launch_whitted(const KArgs& a, bool emit, bool count, hipStream_t stream);
+
+// Enqueue the collision-test hook (rt_debug_intersect).
+hipError_t launch_debug_intersect(const DGeom* geom, int prim, const double* rays, int n,
+                                  double* t_out, uint8_t* hit_out, double* unit_out,
+                                  hipStream_t stream);
+
+}  // namespace rt

@@ -1,0 +1,158 @@
+"""GPU parity: the HIP library (through its C ABI) against the CPU checker on the same
+scene bytes.  Run on the GPU box: python -m pytest tests -m gpu."""
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, scenes
+from tests import oracle_lib
+from tests.parity import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(tracer, prims, lights, params, counters=True):
+    tracer.upload_scene(prims, lights)
+    dev = tracer.render(params, want_counters=counters)
+    ora = oracle_lib.render(prims, lights, params, want_counters=counters)
+    return dev, ora
+
+
+def test_collision_and_normalize_bits(tracer):
+    """TestCollision (sphere, plane) and gmtl normalize on random rays: every double the
+    device produces equals the CPU's bit for bit (division and sqrt are correctly rounded
+    on both)."""
+    prims, lights = scenes.default_scene()
+    tracer.upload_scene(prims, lights)
+    rng = np.random.default_rng(1234)
+    n = 200_000
+    rays = np.empty((n, 6))
+    rays[:, 0:3] = rng.uniform(-3, 3, (n, 3))
+    target = np.array([2.0, 0.5, 10.0]) + rng.normal(0, 0.8, (n, 3))
+    d = target - rays[:, 0:3]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 3:6] = d
+    rays[: n // 10, 3:6] *= rng.uniform(1e-3, 1e3, (n // 10, 1))  # un-normalised directions too
+    for prim in range(len(prims)):
+        t_d, h_d, u_d = tracer.debug_intersect(rays, prim)
+        t_o, h_o, u_o = oracle_lib.intersect(prims, rays, prim)
+        assert np.array_equal(h_d, h_o), f"prim {prim}: hit flags differ"
+        assert np.array_equal(t_d.view(np.uint64), t_o.view(np.uint64)), f"prim {prim}: t bits differ"
+        assert np.array_equal(u_d.view(np.uint64), u_o.view(np.uint64)), f"prim {prim}: normalize bits differ"
+        assert 0 < h_o.sum() < n or prim == 0
+
+
+@pytest.mark.parametrize("size", [(64, 64), (160, 90), (37, 23)])
+@pytest.mark.parametrize("depth", [2, 3, 4, 5, 8])
+def test_default_scene(tracer, size, depth):
+    prims, lights = scenes.default_scene()
+    p = abi.make_params(size[0], size[1], depth)
+    dev, ora = _both(tracer, prims, lights, p)
+    assert_parity(dev, ora, f"default {size} D{depth}")
+
+
+def test_default_scene_reference_size(tracer):
+    """The reference's own configuration: 640x640, MAX_DEPTH 4."""
+    prims, lights = scenes.default_scene()
+    p = abi.make_params(640, 640, 4)
+    dev, ora = _both(tracer, prims, lights, p)
+    assert_parity(dev, ora, "default 640x640 D4")
+    assert int(dev["counters"]["rays"]) == 893544
+
+
+def test_default_scene_4k_depth5(tracer):
+    """The benchmark configuration, compared pixel by pixel with the checker."""
+    prims, lights = scenes.default_scene()
+    p = abi.make_params(3840, 2160, 5)
+    dev, ora = _both(tracer, prims, lights, p)
+    assert_parity(dev, ora, "default 4K D5")
+    assert int(dev["counters"]["rays"]) == 20139306
+
+
+def test_random_spheres(tracer):
+    prims, lights = scenes.random_spheres_scene()
+    assert len(prims) == 1025 and len(lights) == 8
+    p = abi.make_params(96, 54, 5)
+    dev, ora = _both(tracer, prims, lights, p)
+    assert_parity(dev, ora, "1024 spheres 96x54 D5")
+
+
+def test_random_spheres_4k_rows(tracer):
+    """4K frame of the 1024-sphere scene checked on a strided subset of bands (pixels are
+    independent, so a strip is computed exactly as inside the full frame)."""
+    prims, lights = scenes.random_spheres_scene()
+    p = abi.make_params(3840, 2160, 5, band_rows=1, band_first=7, band_step=270, band_count=8)
+    assert abi.strip_rows(p) == 8
+    tracer.upload_scene(prims, lights)
+    dev = tracer.render(p)
+    full_cols = slice(0, 3840, 1)
+    ora = oracle_lib.render(prims, lights, p)
+    assert_parity(dev, ora, "1024 spheres 4K rows")
+
+
+def test_glass_depth8(tracer):
+    prims, lights = scenes.glass_scene()
+    p = abi.make_params(128, 72, 8)
+    dev, ora = _both(tracer, prims, lights, p)
+    assert_parity(dev, ora, "glass 128x72 D8")
+    # the scene must really exercise the deep tree
+    assert int(np.bitwise_count(ora["spawn_mask"]).sum(axis=-1).max()) > 64
+
+
+@pytest.mark.parametrize("band_rows,step", [(1, 2), (8, 2), (8, 8), (16, 3), (5, 4)])
+def test_strips_reassemble(tracer, band_rows, step):
+    """Rendering the frame as `step` interleaved strips gives the same bytes as the
+    whole frame (what the multi-GPU partition relies on)."""
+    prims, lights = scenes.default_scene()
+    w, h, d = 200, 117, 5
+    tracer.upload_scene(prims, lights)
+    full = tracer.render(abi.make_params(w, h, d))
+    n_bands = -(-h // band_rows)
+    got = {k: np.zeros_like(v) for k, v in full.items() if v is not None and k != "counters"}
+    for r in range(step):
+        cnt = len(range(r, n_bands, step))
+        p = abi.make_params(w, h, d, band_rows=band_rows, band_first=r, band_step=step, band_count=cnt)
+        part = tracer.render(p)
+        rows = abi.strip_image_rows(p)
+        assert len(rows) == part["bgr"].shape[0]
+        for k in got:
+            got[k][rows] = part[k]
+    for k in got:
+        assert np.array_equal(got[k], full[k]), k
+
+
+def test_edge_cases(tracer):
+    prims, lights = scenes.default_scene()
+    # no lights, a single object, 1x1 frame
+    tracer.upload_scene(prims[:1], lights[:0])
+    p = abi.make_params(1, 1, 2)
+    dev = tracer.render(p, want_counters=True)
+    ora = oracle_lib.render(prims[:1], lights[:0], p, want_counters=True)
+    assert_parity(dev, ora, "1x1 no lights")
+    # empty partition
+    tracer.upload_scene(prims, lights)
+    p = abi.make_params(32, 32, 4, band_rows=8, band_first=9, band_step=1, band_count=2)
+    dev = tracer.render(p)
+    assert dev["bgr"].shape == (0, 32, 3)
+    # camera inside a sphere, ray origin on a plane
+    inside = prims.copy()
+    inside[1]["p"] = (0.0, 0.0, 0.5)
+    inside[0]["p"] = (0.0, 0.0, 0.0)
+    p = abi.make_params(48, 48, 6)
+    dev, ora = _both(tracer, inside, lights, p)
+    assert_parity(dev, ora, "camera inside sphere")
+
+
+def test_errors(tracer):
+    from raytracer_amd.device import RtError
+
+    prims, lights = scenes.default_scene()
+    tracer.upload_scene(prims, lights)
+    with pytest.raises(RtError):
+        tracer.render(abi.make_params(16, 16, 9))
+    with pytest.raises(RtError):
+        tracer.render(abi.make_params(0, 16, 4))
+    bad = prims.copy()
+    bad[0]["type"] = 7
+    with pytest.raises(RtError):
+        tracer.upload_scene(bad, lights)
+    tracer.upload_scene(prims, lights)
