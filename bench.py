@@ -1,0 +1,331 @@
+#!/usr/bin/env python3
+"""Benchmark of the Whitted trace path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode strips|batch] [--workload NAME]
+
+A step is one frame.  The default workload is the configuration the headline metric is
+quoted on: the reference's default scene at 3840x2160, recursion depth 5.
+
+  N = 1       the whole frame on one GPU.
+  N > 1       launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py
+              --gpus N ...`, one rank per GPU.  mode strips (default): every frame is cut
+              into interleaved 8-row bands, each rank renders its strip and one RCCL gather
+              brings the 8-bit strips to rank 0 (total work fixed: strong scaling).
+              mode batch: frame f of a camera orbit goes to rank f mod N, no collective
+              (work per GPU fixed: weak scaling).
+
+Rank 0 prints ONE JSON line.  value = rays of all frames of all ranks / wall time of the
+timed steps (max over ranks), with scene and buffers resident in HBM before the clock
+starts.  Rays = TraceRay invocations that pass the depth stop, counted by the kernel's
+counter variant in an untimed launch (and equal to the CPU checker's count).
+
+roofline: the path is bound by the FP32/FP64 vector ALUs, not by MFMA or HBM, so `bound`
+is "valu" and `peak` the gfx950 FP32 vector peak (157.3 TFLOP/s).  achieved = algorithmic
+flops of one launch / mean kernel time measured with HIP events around every timed
+launch, on the stream the kernel runs on.  Algorithmic flops = event counts x a fixed
+cost table (see FLOP_TABLE).  `traffic` is the HBM bytes per launch taken from the PMC
+profile committed under profiles/ (null when none matches the workload).
+
+cpu_baseline: the single-thread CPU checker (oracle/, a port of the reference's path)
+timed on this host on whole frames of the same workload, rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from raytracer_amd import abi, scenes, strips  # noqa: E402
+
+PEAK_FP32_VALU_TFLOPS = 157.3
+
+# Flops per event (mul/add/sub/div/sqrt = 1 each), the reference's arithmetic as written.
+FLOP_TABLE = {
+    "sphere_tests": 17,      # L, tca, d2, compare (src/objects.h:125-130)
+    "plane_tests": 14,       # two dots, a subtraction, a division (src/objects.h:92-96)
+    "pixels": 14,            # primary ray: pixel centre + normalisation
+    "hits": 37 + 30 + 16 + 45,  # hit setup, reflection ray, refraction k, combine
+    "refractions": 26,       # refraction ray when k > 0
+    "feelers": 45,           # feeler direction + diffuse term
+    "feelers_occluded": 25,  # occluder normal + transmission factor
+}
+
+WORKLOADS = {
+    # name: (scene builder, width, height, max_depth)
+    "default_4k_d5": (scenes.default_scene, 3840, 2160, 5),
+    "default_640_d4": (scenes.default_scene, 640, 640, 4),
+    "spheres1024_4k_d5": (scenes.random_spheres_scene, 3840, 2160, 5),
+    "glass_4k_d8": (scenes.glass_scene, 3840, 2160, 8),
+    "default_8k_d5": (scenes.default_scene, 7680, 4320, 5),
+}
+
+
+def algorithmic_flops(counters, pixels: int) -> float:
+    f = FLOP_TABLE["pixels"] * pixels
+    for k, c in FLOP_TABLE.items():
+        if k != "pixels":
+            f += c * int(counters[k])
+    return float(f)
+
+
+def cpu_baseline(prims, lights, base, budget_s: float = 12.0):
+    """Time the CPU checker on whole frames of the workload (or on a strided subset of rows
+    when one frame would not fit the budget)."""
+    from tests import oracle_lib
+
+    h = int(base["height"])
+    # probe on every 64th row to size the sample
+    probe = abi.make_params(int(base["width"]), h, int(base["max_depth"]), band_rows=1, band_first=0,
+                            band_step=64, band_count=-(-h // 64))
+    t0 = time.perf_counter()
+    r = oracle_lib.render(prims, lights, probe, want_ids=False, want_masks=False, want_counters=True)
+    dt = time.perf_counter() - t0
+    est_frame = dt * 64
+    if est_frame <= budget_s:
+        frames = max(1, int(budget_s // max(est_frame, 1e-3)))
+        p = abi.make_params(int(base["width"]), h, int(base["max_depth"]))
+        rays = 0
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            r = oracle_lib.render(prims, lights, p, want_ids=False, want_masks=False, want_counters=True)
+            rays += int(r["counters"]["rays"])
+        dt = time.perf_counter() - t0
+        sample = f"{frames} whole frame(s) of the workload"
+        ms_frame = dt / frames * 1e3
+    else:
+        step = max(2, int(math.ceil(est_frame / budget_s)))
+        p = abi.make_params(int(base["width"]), h, int(base["max_depth"]), band_rows=1, band_first=0,
+                            band_step=step, band_count=-(-h // step))
+        t0 = time.perf_counter()
+        r = oracle_lib.render(prims, lights, p, want_ids=False, want_masks=False, want_counters=True)
+        dt = time.perf_counter() - t0
+        rays = int(r["counters"]["rays"])
+        sample = f"every {step}th row of one frame ({abi.strip_rows(p)} of {h} rows)"
+        ms_frame = dt * step * 1e3
+    return {
+        "value": rays / dt / 1e6,
+        "unit": "Mrays/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": sample,
+        "ms_per_frame": ms_frame,
+        "cpu": _cpu_model(),
+    }
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _traffic_bytes(workload: str):
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", choices=("strips", "batch"), default="strips")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="default_4k_d5")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump", default=None, help="rank 0: write the last frame as BMP to this path")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from raytracer_amd.device import DeviceTracer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    builder, width, height, depth = WORKLOADS[args.workload]
+    prims, lights = builder()
+    base = abi.make_params(width, height, depth)
+    tracer = DeviceTracer(local_rank)
+    tracer.upload_scene(prims, lights)
+    stream = torch.cuda.current_stream()
+
+    # ---- what this rank renders per step ------------------------------------------------
+    if args.mode == "strips" or world == 1:
+        mode = "strips"
+        my = strips.rank_params(base, rank, world)
+        scaling = "strong" if world > 1 else "weak"
+    else:
+        mode = "batch"
+        my = base.copy()
+        scaling = "weak"
+    my_rows = abi.strip_rows(my)
+
+    # untimed counter launch: rays and event counts of this rank's share of one frame
+    d_cnt = torch.zeros(8, dtype=torch.int64, device=device)
+    scratch = torch.zeros((max(my_rows, 1), width, 3), dtype=torch.uint8, device=device)
+    pc = my.copy()
+    pc["flags"] = abi.RT_FLAG_COUNTERS
+    tracer.render_device(pc, stream.cuda_stream, scratch.data_ptr(), d_counters=d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    cnt_host = d_cnt.cpu().numpy().astype(np.uint64)
+    counters = {f: int(cnt_host[i]) for i, f in enumerate(abi.COUNTER_FIELDS)}
+    my_flops = algorithmic_flops(counters, my_rows * width)
+    my_rays = counters["rays"]
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    step_no = [0]
+
+    def render_strip(params, out):
+        i = step_no[0] - args.warmup
+        if 0 <= i < args.steps:
+            ev[i][0].record(stream)
+        tracer.render_device(params, stream.cuda_stream, out.data_ptr())
+        if 0 <= i < args.steps:
+            ev[i][1].record(stream)
+
+    if mode == "strips":
+        gatherer = strips.StripGatherer(base, render_strip, device)
+
+        def step():
+            slot = gatherer.submit()
+            step_no[0] += 1
+            return slot
+    else:
+        # orbit batch: this rank's frames are different views of the scene; the scene of
+        # every view is uploaded before the clock starts, one context per view in flight
+        # is not needed because uploads are tiny and synchronous, so views are pre-built.
+        n_views = 8
+        views = []
+        for v in range(n_views):
+            t = DeviceTracer(local_rank)
+            pr, lt = scenes.orbit_scene(prims, lights, 2 * math.pi * (rank * n_views + v) / (world * n_views))
+            t.upload_scene(pr, lt)
+            views.append(t)
+        out = [torch.zeros((height, width, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+
+        def step():
+            i = step_no[0] - args.warmup
+            if 0 <= i < args.steps:
+                ev[i][0].record(stream)
+            views[step_no[0] % n_views].render_device(base, stream.cuda_stream, out[step_no[0] & 1].data_ptr())
+            if 0 <= i < args.steps:
+                ev[i][1].record(stream)
+            step_no[0] += 1
+            return 0
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if mode == "strips":
+        gatherer.drain()
+    fence()
+    t0 = time.perf_counter()
+    last = 0
+    for _ in range(args.steps):
+        last = step()
+    if mode == "strips":
+        gatherer.drain()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+
+    # max over ranks of the wall time, sum over ranks of the rays
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([my_rays], dtype=torch.int64, device=device)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays_per_step = int(r.item())
+    else:
+        rays_per_step = my_rays
+
+    if rank == 0:
+        if args.dump and mode == "strips":
+            from raytracer_amd.frame import write_bmp
+
+            write_bmp(args.dump, gatherer.frame(last).cpu().numpy())
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays_per_step * args.steps / elapsed / 1e6
+        achieved = my_flops / (kernel_ms * 1e-3) / 1e12
+        fb_bytes = my_rows * width * 3
+        line = {
+            "metric": "Mrays/s (primary+secondary rays traced)",
+            "value": value,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": scaling,
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {width}x{height}, max_depth {depth}, {len(prims)} objects, "
+                            f"{len(lights)} lights",
+                "mode": mode if world > 1 else "single",
+                "rays_per_frame": rays_per_step,
+                "band_rows": strips.DEFAULT_BAND_ROWS,
+            },
+            "roofline": {
+                "bound": "valu",
+                "achieved": achieved,
+                "peak": PEAK_FP32_VALU_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                "traffic": _traffic_bytes(args.workload) if world == 1 else None,
+                "kernel": "whitted_kernel<0,false>",
+                "kernel_ms": kernel_ms,
+                "algorithmic_flops_per_launch": my_flops,
+                "framebuffer_write_GBps": fb_bytes / (kernel_ms * 1e-3) / 1e9,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(prims, lights, base)
+            line["config"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
