@@ -1,0 +1,116 @@
+"""The C ABI without a GPU: the library loads, exports every symbol the header declares,
+the struct layouts agree between C and Python, the pure-host entry points work, and
+creating a context without a device fails loudly instead of falling back."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, device
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rt_hip.h")
+
+
+def _declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = device.load_library()
+    names = _declared_functions()
+    assert set(names) == set(device.EXPORTS)
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_struct_layout_matches_header(tmp_path):
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "rt_hip.h"\n'
+        "int main(void){\n"
+        'printf("%zu %zu %zu %zu\\n", sizeof(rt_prim), sizeof(rt_light), sizeof(rt_params), sizeof(rt_counters));\n'
+        'printf("%zu %zu %zu %zu %zu\\n", offsetof(rt_prim,p), offsetof(rt_prim,q), offsetof(rt_prim,kd),'
+        " offsetof(rt_prim,reflectivity), offsetof(rt_prim,ambient_intensity));\n"
+        'printf("%zu %zu %zu %zu\\n", offsetof(rt_params,max_depth), offsetof(rt_params,flags),'
+        " offsetof(rt_params,fov_deg), offsetof(rt_params,bgr));\n"
+        'printf("%zu %zu\\n", offsetof(rt_counters,rays), offsetof(rt_counters,refractions));\n'
+        "return 0;}\n"
+    )
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    got = [int(v) for v in out]
+    P, L, R, C = abi.PRIM_DTYPE, abi.LIGHT_DTYPE, abi.PARAMS_DTYPE, abi.COUNTERS_DTYPE
+    want = [
+        P.itemsize, L.itemsize, R.itemsize, C.itemsize,
+        P.fields["p"][1], P.fields["q"][1], P.fields["kd"][1], P.fields["reflectivity"][1],
+        P.fields["ambient_intensity"][1],
+        R.fields["max_depth"][1], R.fields["flags"][1], R.fields["fov_deg"][1], R.fields["bgr"][1],
+        C.fields["rays"][1], C.fields["refractions"][1],
+    ]
+    assert got == want
+
+
+def test_host_only_entry_points():
+    lib = device.load_library()
+    assert lib.rt_version().decode().count(".") == 1
+    for d in range(1, abi.RT_MAX_DEPTH + 1):
+        assert lib.rt_mask_words(d) == abi.mask_words(d)
+    assert lib.rt_mask_words(0) == abi.RT_ERR_ARG and lib.rt_mask_words(9) == abi.RT_ERR_ARG
+    for (h, br, first, step, count) in ((2160, 8, 3, 8, 34), (61, 8, 0, 1, 8), (61, 8, 7, 2, 1), (61, 8, 9, 1, 4),
+                                        (17, 5, 1, 2, 2)):
+        p = abi.make_params(40, h, 5, band_rows=br, band_first=first, band_step=step, band_count=count)
+        assert lib.rt_strip_rows(p.ctypes.data) == abi.strip_rows(p)
+    bad = abi.make_params(40, 40, 1)
+    assert lib.rt_strip_rows(bad.ctypes.data) == abi.RT_ERR_ARG
+    assert lib.rt_strip_rows(None) == abi.RT_ERR_ARG
+
+
+def _have_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the behaviour on a machine without a GPU")
+def test_no_device_fails_loudly():
+    lib = device.load_library()
+    h = ctypes.c_void_p()
+    rc = lib.rt_create(0, ctypes.byref(h))
+    assert rc == abi.RT_ERR_HIP and not h.value
+    assert b"no HIP device" in lib.rt_last_error(None)
+    with pytest.raises(device.RtError):
+        device.DeviceTracer(0)
+    assert lib.rt_create(0, None) == abi.RT_ERR_ARG
+
+
+def test_null_context_is_rejected():
+    lib = device.load_library()
+    p = abi.make_params(8, 8, 4)
+    buf = np.zeros(8 * 8 * 3, dtype=np.uint8)
+    assert lib.rt_render(None, p.ctypes.data, buf.ctypes.data, None, None, None, None) == abi.RT_ERR_ARG
+    assert lib.rt_upload_scene(None, None, 0, None, 0) == abi.RT_ERR_ARG
+    assert lib.rt_render_device(None, p.ctypes.data, None, None, None, None, None, None) == abi.RT_ERR_ARG
+    assert lib.rt_debug_intersect(None, None, 0, 0, None, None, None) == abi.RT_ERR_ARG
+    lib.rt_destroy(None)
+    assert lib.rt_last_error(None) is not None
+
+
+def test_product_package_never_touches_the_checker():
+    """Nothing under raytracer_amd/ (Python, C++ or HIP) may import, include, link or load
+    anything from oracle/."""
+    pkg = os.path.join(ROOT, "raytracer_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, fn)

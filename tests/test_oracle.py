@@ -1,0 +1,164 @@
+"""The CPU checker against everything that can pin it without a GPU: the event counts of
+the surveyed reference build, analytic known answers, the committed golden frames and
+structural properties of the ray tree."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, scenes
+from tests import oracle_lib
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _probe_rows():
+    with open(os.path.join(GOLDEN, "survey_probe_counts.json")) as f:
+        return json.load(f)["rows"]
+
+
+@pytest.mark.parametrize("row", _probe_rows(), ids=lambda r: f"{r['width']}x{r['height']}_d{r['max_depth']}")
+def test_event_counts_match_surveyed_reference_build(row):
+    """rays / hits / sphere tests / plane tests / feelers / occluded feelers of the default
+    scene equal the counts of the instrumented reference sources."""
+    prims, lights = scenes.default_scene()
+    p = abi.make_params(row["width"], row["height"], row["max_depth"])
+    r = oracle_lib.render(prims, lights, p, want_ids=False, want_masks=False, want_counters=True)
+    for k in ("rays", "hits", "sphere_tests", "plane_tests", "feelers", "feelers_occluded"):
+        assert int(r["counters"][k]) == row[k], k
+
+
+def test_golden_frames():
+    prims, lights = scenes.default_scene()
+    z = np.load(os.path.join(GOLDEN, "oracle_frames.npz"))
+    builders = {"default": (prims, lights), "glass": scenes.glass_scene(), "spheres1024": scenes.random_spheres_scene()}
+    keys = sorted({k.split("/")[0] for k in z.files})
+    assert len(keys) == 10
+    for key in keys:
+        name, size, d = key.split("_")
+        w, h = (int(v) for v in size.split("x"))
+        pr, lt = builders[name]
+        r = oracle_lib.render(pr, lt, abi.make_params(w, h, int(d[1:])))
+        for k in ("bgr", "hit_id", "hit_mask", "spawn_mask"):
+            assert np.array_equal(r[k], z[f"{key}/{k}"]), f"{key}/{k}"
+
+
+def test_golden_hash_reference_size():
+    with open(os.path.join(GOLDEN, "oracle_hashes.json")) as f:
+        want = json.load(f)
+    prims, lights = scenes.default_scene()
+    assert hashlib.sha256(prims.tobytes() + lights.tobytes()).hexdigest() == want["scene_bytes"]["default"]
+    sp, sl = scenes.random_spheres_scene()
+    assert hashlib.sha256(sp.tobytes() + sl.tobytes()).hexdigest() == want["scene_bytes"]["spheres1024"]
+    gp, gl = scenes.glass_scene()
+    assert hashlib.sha256(gp.tobytes() + gl.tobytes()).hexdigest() == want["scene_bytes"]["glass"]
+    r = oracle_lib.render(prims, lights, abi.make_params(640, 640, 4), want_counters=True)
+    h = hashlib.sha256()
+    for k in ("bgr", "hit_id", "hit_mask", "spawn_mask"):
+        h.update(np.ascontiguousarray(r[k]).tobytes())
+    rec = want["default_640x640_d4"]
+    assert h.hexdigest() == rec["sha256_bgr_hitid_hitmask_spawnmask"]
+    assert {f: int(r["counters"][f]) for f in abi.COUNTER_FIELDS} == rec["counters"]
+
+
+def test_known_answers_intersection():
+    prims, _ = scenes.default_scene()
+    # sphere 1: centre (2, .5, 10), r 1.  A ray from the origin straight at the centre
+    # meets it at |c| - 1; from inside the far side is returned; pointing away misses.
+    c = np.array([2.0, 0.5, 10.0])
+    dist = float(np.sqrt(c @ c))
+    rays = np.array(
+        [
+            np.concatenate([[0, 0, 0], c / dist]),
+            np.concatenate([c, [0, 0, 1]]),
+            np.concatenate([[0, 0, 0], -c / dist]),
+            [2.0, 0.5, 0.0, 0.0, 0.0, 1.0],  # axis-aligned: exact arithmetic
+            [3.0, 0.5, 0.0, 0.0, 0.0, 1.0],  # tangent: d2 == r2 -> hit with thc = 0
+            [3.0 + 1e-9, 0.5, 0.0, 0.0, 0.0, 1.0],
+        ]
+    )
+    t, hit, _ = oracle_lib.intersect(prims, rays, 1)
+    assert list(hit) == [1, 1, 0, 1, 1, 0]
+    assert abs(t[0] - (dist - 1)) < 1e-12
+    assert t[1] == 1.0  # centre behind-test passes with tca = 0; t = -1 -> 0 + 1
+    assert t[3] == 9.0 and t[4] == 10.0
+    # plane 0: y = -3, normal +y.  Straight down from the origin: t = 3.  Parallel: miss.
+    rays = np.array([[0, 0, 0, 0, -1, 0], [0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 1, 0], [0, -3, 0, 0, -1, 0],
+                     [0, 0, 0, 1, -5e-7, 0]], dtype=float)
+    t, hit, _ = oracle_lib.intersect(prims, rays, 0)
+    assert list(hit) == [1, 0, 0, 0, 0]
+    assert t[0] == 3.0
+
+
+def test_known_answers_normalize_and_literals():
+    prims, lights = scenes.default_scene()
+    _, _, unit = oracle_lib.intersect(prims, np.array([[0, 0, 0, 3, 4, 0], [0, 0, 0, 0, 0, 0]], dtype=float), 0)
+    assert np.array_equal(unit[0], [3 / 5, 4 / 5, 0.0])
+    assert np.array_equal(unit[1], [0.0, 0.0, 0.0])  # zero length: left alone
+    # float literals of the reference's scene, widened to double
+    assert prims[1]["transparency"] == float(np.float32(0.9)) != 0.9
+    assert prims[2]["reflectivity"] == float(np.float32(0.2))
+    assert prims[0]["ambient_intensity"] == float(np.float32(0.3))
+    assert lights[1]["intensity"] == float(np.float32(0.3))
+    assert prims[1]["reflectivity"] == 0.7 and prims[1]["refraction_index"] == 1.1
+    assert tuple(prims[0]["q"]) == (0.0, 1.0, 0.0)
+
+
+def test_tree_structure_properties():
+    """Heap-numbered masks: the root is always spawned; only spawned nodes can hit; a child
+    is spawned only under a hit parent (reflection always while depth allows, refraction
+    only sometimes); the ray counter equals the popcount of the spawn masks."""
+    prims, lights = scenes.glass_scene()
+    for d in (2, 5, 8):
+        r = oracle_lib.render(prims, lights, abi.make_params(64, 36, d), want_counters=True)
+        words = abi.mask_words(d)
+        sm = np.zeros(r["spawn_mask"].shape[:2], dtype=object)
+        hm = np.zeros_like(sm)
+        for w in range(words):
+            sm += r["spawn_mask"][..., w].astype(object) << (32 * w)
+            hm += r["hit_mask"][..., w].astype(object) << (32 * w)
+        assert int(np.bitwise_count(r["spawn_mask"]).sum()) == int(r["counters"]["rays"])
+        assert int(np.bitwise_count(r["hit_mask"]).sum()) == int(r["counters"]["hits"])
+        for s, h, hid in zip(sm.ravel(), hm.ravel(), r["hit_id"].ravel()):
+            assert s & 2 and not s & 1
+            assert h & ~s == 0
+            assert (hid >= 0) == bool(h & 2)
+            for node in range(1, 1 << (d - 1)):
+                if 2 * node < (1 << (d - 1)):
+                    refl, refr = (s >> (2 * node)) & 1, (s >> (2 * node + 1)) & 1
+                    hit = (h >> node) & 1
+                    assert refl == hit
+                    assert refr <= hit
+
+
+def test_strips_cover_frame_exactly():
+    prims, lights = scenes.default_scene()
+    w, h, d = 96, 61, 5
+    full = oracle_lib.render(prims, lights, abi.make_params(w, h, d))
+    for band_rows, world in ((8, 2), (8, 8), (1, 3), (16, 5)):
+        got = np.zeros_like(full["bgr"])
+        seen = np.zeros(h, dtype=int)
+        for r in range(world):
+            nb = -(-h // band_rows)
+            p = abi.make_params(w, h, d, band_rows=band_rows, band_first=r, band_step=world,
+                                band_count=len(range(r, nb, world)))
+            part = oracle_lib.render(prims, lights, p)
+            rows = abi.strip_image_rows(p)
+            assert oracle_lib.lib().oracle_strip_rows(p.ctypes.data) == len(rows) == abi.strip_rows(p)
+            got[rows] = part["bgr"]
+            seen[rows] += 1
+        assert (seen == 1).all()
+        assert np.array_equal(got, full["bgr"])
+
+
+def test_depth_limit_and_background():
+    prims, lights = scenes.default_scene()
+    r2 = oracle_lib.render(prims, lights, abi.make_params(32, 32, 2))
+    assert int(np.bitwise_count(r2["spawn_mask"]).max()) == 1  # only the primary ray is traced
+    sky = r2["hit_id"] < 0
+    want = np.array([int(0.92 * 255), int(0.76 * 255), int(0.58 * 255)], dtype=np.uint8)  # B,G,R truncated
+    assert (r2["bgr"][sky] == want).all()
+    with pytest.raises(ValueError):
+        oracle_lib.render(prims, lights, abi.make_params(32, 32, 9))
