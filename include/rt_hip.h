@@ -74,6 +74,10 @@ typedef struct rt_light {
 
 /* rt_params.flags */
 #define RT_FLAG_COUNTERS 1u   /* also count events into rt_counters (slower kernel)      */
+#define RT_FLAG_EXACT 2u      /* render every pixel with the double-precision kernel; by
+                                 default a single-precision pass with certified decisions
+                                 runs first and only the pixels it cannot certify are
+                                 rendered in double.  RT_FLAG_COUNTERS implies this.     */
 
 /*
  * Per-render parameters: the values the reference hard-wires in Tracer()/main()
@@ -169,6 +173,37 @@ int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id,
 int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_bgr,
                      int32_t* d_hit_id, uint32_t* d_hit_mask, uint32_t* d_spawn_mask,
                      rt_counters* d_counters);
+
+/*
+ * Statistics since rt_create: how many pixels the single-precision pass handed to the
+ * double-precision kernel, over how many renders that used the single-precision pass.
+ * Waits for the context's outstanding work (call it after synchronising other streams).
+ */
+typedef struct rt_stats {
+    uint64_t requeued_pixels;
+    uint64_t fast_renders;
+} rt_stats;
+int rt_get_stats(rt_ctx* ctx, rt_stats* out);
+
+/*
+ * Test hook: multiply every error bound of the single-precision pass by `guard`.
+ * 1 (the default) = bounds as derived, decisions certified.  0 = no certification: the
+ * pass then decides on raw float comparisons and its results may differ from the
+ * reference; tests use it to show that the bounds are what makes the pass exact.
+ */
+int rt_debug_set_guard(rt_ctx* ctx, float guard);
+
+/*
+ * Diagnostic hook: render the partition and report, per pixel (rows*width bytes, strip
+ * order), why the single-precision pass handed it to the double-precision kernel:
+ * 0 = every comparison was certified; otherwise (depth << 4) | cause with cause
+ * 2 = two hit candidates too close to order, 3 = inside/outside test (dot(n, d) near 0),
+ * 5 = total-reflection test (k near 0), 6..9 = a collision test of the nearest-hit loop,
+ * 10..13 = a collision test of a shadow feeler; within those: +0 sphere, d2 against r^2 or
+ * tca against 0; +1 sphere, near root against 0; +2 plane, |denom| against 1e-6; +3 plane,
+ * t against 0.  p->flags must be 0.
+ */
+int rt_debug_flag_reasons(rt_ctx* ctx, const rt_params* p, uint8_t* reasons);
 
 /*
  * Test hooks: run the device versions of the reference's collision tests and of the

@@ -14,7 +14,8 @@ namespace rt {
 
 // Geometry of one collider + the one material value a shadow feeler needs.
 // r2 < 0 marks a plane (q = unit normal as stored by the Plane constructor);
-// otherwise a sphere with r2 = radius*radius (std::pow(radius_,2), src/objects.h:125).
+// otherwise a sphere with r2 = radius*radius (std::pow(radius_,2), src/objects.h:125) and
+// q = {1/radius, radius, 0} (used by the fast pass only).
 struct DGeom {
     double p[3];
     double q[3];
@@ -29,7 +30,7 @@ struct DMat {
     double transparency;
     double refraction_index;
     double ambient_intensity;
-    double pad;
+    double pad;  // 1.0 / refraction_index (used by the fast pass)
 };
 
 // One point light; ci = light_color * double(intensity) (src/objects.h:54-56).
@@ -45,6 +46,7 @@ static_assert(sizeof(DGeom) == 64 && sizeof(DMat) == 64 && sizeof(DLight) == 64,
 constexpr int kStackFields = 8;
 constexpr int kWavesPerBlock = 4;
 constexpr int kTile = 8;  // a wave renders an 8x8 pixel tile
+constexpr int kQueueBlocks = 1024;  // fixed grid of the queue pass (4 waves each)
 
 struct KArgs {
     const DGeom* geom;
@@ -64,7 +66,69 @@ struct KArgs {
     double pw, ph;             // pixel pitch (src/view_frustum.h:33-34)
     double bgr_c[3];
     double inv_depth[RT_MAX_DEPTH + 1];  // 1.0/depth for depth 1..max_depth-1
+    // Queue mode (exact re-evaluation of the pixels the single-precision pass could not
+    // decide): pixel numbers (strip row * width + x) and their count, both on the device.
+    const uint32_t* queue;
+    const uint32_t* queue_count;
+    uint32_t* queue_count_next;    // zeroed by the queue pass for the following render
+    unsigned long long* stats;     // [0] += pixels re-evaluated, [1] += renders
 };
+
+// ---- single-precision pass ---------------------------------------------------------
+// 48-byte primitive record: {p.xyz, r2 | -1 for a plane}, {q.xyz (plane normal),
+// transparency}, {cerr = 2^-24 * |p|_1, radius, 0, 0}; one s_load_dwordx8 + s_load_dwordx4.
+struct FGeom {
+    float p[3], r2;
+    float q[3], transparency;
+    float cerr, radius, pad[2];
+};
+// Material gathered per lane on a hit.
+struct FMat {
+    float kd[3], reflectivity;
+    float transparency, ri, inv_ri, ambient;
+};
+// Light: position, 2^-24 * |pos|_1, colour * intensity.
+struct FLight {
+    float pos[3], lerr;
+    float ci[3], pad;
+};
+static_assert(sizeof(FGeom) == 48 && sizeof(FMat) == 32 && sizeof(FLight) == 32, "record size");
+
+constexpr int kFastStackFields = 8;  // doubles: origin, direction, {weight, eo}, {ed, node}
+
+struct FArgs {
+    const FGeom* geom;
+    const FMat* mat;
+    const FLight* lights;
+    const DGeom* geom64;       // double tables (for spheres q = {1/r, r, 0})
+    const DMat* mat64;
+    const DLight* lights64;
+    uint8_t* bgr;
+    int32_t* hit_id;
+    uint32_t* hit_mask;
+    uint32_t* spawn_mask;
+    uint32_t* queue;           // pixels handed to the exact pass
+    uint32_t* queue_count;
+    uint8_t* reason;           // diagnostics (nullable): why a pixel was handed over, 0 = certified
+    unsigned long long* stamps; // diagnostic build only (nullable): per-segment cycle sums
+    int32_t n_prims, n_lights;
+    int32_t width, height, max_depth;
+    int32_t band_rows, band_first, band_step;
+    int32_t rows, tiles_x, tiles_y, mask_words;
+    double pw64, ph64;         // pixel pitch (src/view_frustum.h:33-34)
+    float bgr_c[3];
+    float inv_depth[RT_MAX_DEPTH + 1];
+    float scene_p1max;         // max over primitives of |p|_1
+    float guard;               // multiplier on every error bound (1 = as derived)
+};
+
+inline size_t fast_stack_lds_bytes(int max_depth) {
+    int entries = max_depth - 2;
+    if (entries < 1) entries = 1;
+    return (size_t)kWavesPerBlock * entries * kFastStackFields * 64 * sizeof(double);
+}
+
+hipError_t launch_whitted_fast(const FArgs& a, bool emit, hipStream_t stream);
 
 // Bytes of dynamic LDS one block needs for a given max_depth.
 inline size_t stack_lds_bytes(int max_depth) {
@@ -76,6 +140,9 @@ inline size_t stack_lds_bytes(int max_depth) {
 // Enqueue the render of one strip on `stream`.  emit = write hit_id/masks (pointers in
 // `a` that are null are skipped), count = add event counts to a.counters.
 hipError_t launch_whitted(const KArgs& a, bool emit, bool count, hipStream_t stream);
+
+// Same kernel over the pixels listed in a.queue (count read on the device).
+hipError_t launch_whitted_queue(const KArgs& a, bool emit, hipStream_t stream);
 
 // Enqueue the collision-test hook (rt_debug_intersect).
 hipError_t launch_debug_intersect(const DGeom* geom, int prim, const double* rays, int n,

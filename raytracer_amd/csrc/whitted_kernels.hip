@@ -144,25 +144,15 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
     return s;
 }
 
+// The whole walk of one pixel: lane-private except for the scalar scene loads.
+// (x, k) = column and strip row; `have` is false for lanes without a pixel.
 // MW = mask words kept per lane (0: neither hit_id nor masks are produced).
 template <int MW, bool COUNT>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void whitted_kernel(KArgs a) {
-    extern __shared__ double lds_stack[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int entries = a.max_depth > 3 ? a.max_depth - 2 : 1;
-    double* stk = lds_stack + (size_t)wave * entries * kStackFields * 64 + lane;
-
+__device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const int k, bool have, double* stk,
+                                            uint32_t (&cnt)[8]) {
     const cdata_t geom = (cdata_t)(const double*)a.geom;
     const cdata_t lights = (cdata_t)(const double*)a.lights;
-
-    // tile -> pixel
-    const int tile = blockIdx.x * kWavesPerBlock + wave;
-    const int tx = tile % a.tiles_x;
-    const int ty = tile / a.tiles_x;
-    const int x = tx * kTile + (lane & 7);
-    const int k = ty * kTile + (lane >> 3);  // row in strip order
-    bool have = (ty < a.tiles_y) && (x < a.width) && (k < a.rows);
+    const bool inside = have;
     const int band = k / a.band_rows;
     const int y = (a.band_first + band * a.band_step) * a.band_rows + (k - band * a.band_rows);
 
@@ -185,7 +175,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void whitted_kernel(KArgs a) {
     int32_t first_hit = -1;
     uint32_t hmask[MW > 0 ? MW : 1] = {0};
     uint32_t smask[MW > 0 ? MW : 1] = {0};
-    uint32_t c_rays = 0, c_phits = 0, c_hits = 0, c_sph = 0, c_pln = 0, c_feel = 0, c_occ = 0, c_refr = 0;
+    uint32_t &c_rays = cnt[0], &c_phits = cnt[1], &c_hits = cnt[2], &c_sph = cnt[3], &c_pln = cnt[4],
+             &c_feel = cnt[5], &c_occ = cnt[6], &c_refr = cnt[7];
 
     while (have) {
         const int level = 32 - __builtin_clz(node);  // the reference's `depth`
@@ -335,7 +326,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void whitted_kernel(KArgs a) {
         }
     }
 
-    const bool inside = (ty < a.tiles_y) && (x < a.width) && (k < a.rows);
     if (inside) {
         const size_t px = (size_t)k * a.width + x;
         uint8_t* dst = a.bgr + 3 * px;  // src/screen.h:62-64
@@ -351,13 +341,66 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void whitted_kernel(KArgs a) {
             }
         }
     }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void flush_counters(const KArgs& a, const uint32_t (&cnt)[8], int lane) {
     if (COUNT) {
-        unsigned long long s[8] = {wave_sum(c_rays), wave_sum(c_phits), wave_sum(c_hits), wave_sum(c_sph),
-                                   wave_sum(c_pln), wave_sum(c_feel), wave_sum(c_occ), wave_sum(c_refr)};
+        unsigned long long s[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = wave_sum(cnt[i]);
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) atomicAdd(&a.counters[i], s[i]);
         }
+    }
+}
+
+// One wave per 8x8 pixel tile of the strip.
+template <int MW, bool COUNT>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void whitted_kernel(KArgs a) {
+    extern __shared__ double lds_stack[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int entries = a.max_depth > 3 ? a.max_depth - 2 : 1;
+    double* stk = lds_stack + (size_t)wave * entries * kStackFields * 64 + lane;
+    const int tile = blockIdx.x * kWavesPerBlock + wave;
+    const int tx = tile % a.tiles_x;
+    const int ty = tile / a.tiles_x;
+    const int x = tx * kTile + (lane & 7);
+    const int k = ty * kTile + (lane >> 3);  // row in strip order
+    const bool have = (ty < a.tiles_y) && (x < a.width) && (k < a.rows);
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    trace_pixel<MW, COUNT>(a, x, k, have, stk, cnt);
+    flush_counters<COUNT>(a, cnt, lane);
+}
+
+// The same walk over the pixels listed in a.queue: every wave takes 64 queued pixels at
+// a time until the list is exhausted.  The count lives on the device (it was produced by
+// the kernel before this one on the stream), so the grid is fixed and most waves of a
+// short list leave at once.
+template <int MW>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void whitted_queue_kernel(KArgs a) {
+    extern __shared__ double lds_stack[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int entries = a.max_depth > 3 ? a.max_depth - 2 : 1;
+    double* stk = lds_stack + (size_t)wave * entries * kStackFields * 64 + lane;
+    const uint32_t count = *a.queue_count;
+    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *a.queue_count_next = 0;
+        atomicAdd(&a.stats[0], (unsigned long long)count);
+        atomicAdd(&a.stats[1], 1ull);
+    }
+    for (uint32_t base = (blockIdx.x * kWavesPerBlock + wave) * 64u; base < count; base += n_waves * 64u) {
+        const uint32_t i = base + lane;
+        const bool have = i < count;
+        const uint32_t px = have ? a.queue[i] : 0u;
+        const int k = (int)(px / (uint32_t)a.width);
+        const int x = (int)(px - (uint32_t)k * (uint32_t)a.width);
+        uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        trace_pixel<MW, false>(a, x, k, have, stk, cnt);
     }
 }
 
@@ -387,6 +430,23 @@ hipError_t launch_whitted(const KArgs& a, bool emit, bool count, hipStream_t str
             case 2: return launch_t<2, false>(a, stream);
             case 4: return launch_t<4, false>(a, stream);
         }
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int MW>
+static hipError_t launch_q(const KArgs& a, hipStream_t stream) {
+    const size_t lds = stack_lds_bytes(a.max_depth);
+    hipLaunchKernelGGL((whitted_queue_kernel<MW>), dim3(kQueueBlocks), dim3(64 * kWavesPerBlock), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_whitted_queue(const KArgs& a, bool emit, hipStream_t stream) {
+    switch (emit ? a.mask_words : 0) {
+        case 0: return launch_q<0>(a, stream);
+        case 1: return launch_q<1>(a, stream);
+        case 2: return launch_q<2>(a, stream);
+        case 4: return launch_q<4>(a, stream);
     }
     return hipErrorInvalidValue;
 }
