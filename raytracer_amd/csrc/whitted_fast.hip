@@ -150,17 +150,12 @@ __device__ __forceinline__ void prepare_ray(RayF& r, float U, float scene_p1max)
 // The common outcome, a miss by a wide margin, is decided from 14 operations and leaves
 // through a wave-uniform branch when it holds for every active lane.
 __device__ __forceinline__ int sphere_test(const FGeomS& g, const RayF& r, float U, float& t, float& te) {
+    // straight-line: every lane evaluates everything, the outcome is selected at the end
+    // (no exec-mask juggling; only the survivors of the certain-miss filter get here)
     const F3 L = g.p - r.o;
     const float tca = dot(L, r.d);
     const F3 P = madd(L, r.d, -tca);
     const float d2 = dot(P, P);
-    // far miss: behind the origin by more than any tca error, or |P| > r + eP, which
-    // follows from d2 > 2 r2 + 2 eP^2
-    const bool far = tca < -r.etb || __builtin_fmaf(-2.01f, g.r2, d2) > r.far2;
-    if (__builtin_amdgcn_ballot_w64(!far) == 0ull) return kMiss;
-    __asm__ volatile("" ::: "memory");   // keep the rest from being hoisted above the branch
-    if (far) return kMiss;
-
     const float S1 = l1(L);
     const float eL = r.eo + g.cerr + U * S1;
     const float et = __builtin_fmaf(S1, r.ed3, eL);
@@ -168,53 +163,109 @@ __device__ __forceinline__ int sphere_test(const FGeomS& g, const RayF& r, float
     const float P1 = l1(P);
     const float e2 = __builtin_fmaf(2.0f * P1 + eP, eP, 6.0f * U * (d2 + g.r2)) + 1e-14f * S1 * S1;
     const float m = g.r2 - d2;
-    if (m < -e2 || tca < -et) return kMiss;          // d2 > r2 or tca < 0, certainly
-    if (!(m > e2 && tca > et)) return kUnsure + 0;
-    const float thc = sqrt_(m);
+    const bool miss = (m < -e2) | (tca < -et);        // d2 > r2 or tca < 0, certainly
+    const bool through = (m > e2) & (tca > et);       // d2 < r2 and tca > 0, certainly
+    const float thc = sqrt_(__builtin_fmaxf(m, 1.0e-30f));
     const float eh = e2 * rcp(thc) * 1.01f + 2.0f * U * thc;
     const float tm = tca - thc;
     const float ett = et + eh + U * (__builtin_fabsf(tca) + thc);
-    if (tm > ett) t = tm;                            // t >= 0: the near root
-    else if (tm < -ett) t = tca + thc;               // origin inside: the far root
-    else return kUnsure + 4;
+    const bool near_root = tm > ett;                  // t >= 0: the near root
+    const bool far_root = tm < -ett;                  // origin inside: the far root
+    t = near_root ? tm : tca + thc;
     te = ett;
-    return kHit;
+    const int st_roots = (near_root | far_root) ? kHit : (kUnsure + 4);
+    return miss ? kMiss : (through ? st_roots : (kUnsure + 0));
 }
 
 // Plane::TestCollision (src/objects.h:91-102) in float with certified branches.
 //   denom = d.n:  |denom - denom*| <= ed + 4U =: eden                  (n~ = float(n))
 //   num = (p0 - o).n: |num - num*| <= eo + |p0~ - p0| + 5U |p0 - o| <= en_ray + 6 cerr =: en
 //   t = num/denom: |t - t*| <= (en + |t| eden)/(|denom| - eden) + 4U|t|
-// Certain miss without a division: num and denom certainly of opposite signs (t* < 0;
-// if |denom*| <= 1e-6 the reference misses as well).
 __device__ __forceinline__ int plane_test(const FGeomS& g, const RayF& r, float U, float& t, float& te) {
     const float denom = dot(r.d, g.q);
-    const F3 diff = g.p - r.o;
-    const float num = dot(diff, g.q);
+    const float num = dot(g.p - r.o, g.q);
     const float en = __builtin_fmaf(6.0f, g.cerr, r.en_ray);
-    const bool away = (num < -en && denom > r.eden) || (num > en && denom < -r.eden);
-    if (__builtin_amdgcn_ballot_w64(!away) == 0ull) return kMiss;
-    __asm__ volatile("" ::: "memory");   // keep the rest from being hoisted above the branch
-    if (away) return kMiss;
-
     const float ad = __builtin_fabsf(denom);
-    if (ad + r.eden < 0.999999e-6f) return kMiss;    // |denom*| <= 1e-6
-    if (!(ad > 1.000001e-6f + r.eden)) return kUnsure + 8;
+    const bool parallel = ad + r.eden < 0.999999e-6f;          // |denom*| <= 1e-6: no hit
+    const bool crossing = ad > 1.000001e-6f + r.eden;          // |denom*| > 1e-6
     const float tt = num * rcp(denom);
     const float at = __builtin_fabsf(tt);
-    const float ett = __builtin_fmaf(at, r.eden, en) * rcp(ad - r.eden) * 1.01f + 4.0f * U * at;
-    if (tt > ett) {
-        t = tt;
-        te = ett;
-        return kHit;
-    }
-    if (tt < -ett) return kMiss;                     // t* < 0
-    return kUnsure + 12;
+    const float ett = __builtin_fmaf(at, r.eden, en) * rcp(__builtin_fmaxf(ad - r.eden, 1.0e-30f)) * 1.01f + 4.0f * U * at;
+    t = tt;
+    te = ett;
+    const int st_t = (tt > ett) ? kHit : ((tt < -ett) ? kMiss : (kUnsure + 12));
+    return parallel ? kMiss : (crossing ? st_t : (kUnsure + 8));
 }
 
 __device__ __forceinline__ int test_prim(const FGeomS& g, const RayF& r, float U, float& t, float& te) {
     if (g.r2 < 0.0f) return plane_test(g, r, U, t, te);  // wave-uniform branch
     return sphere_test(g, r, U, t, te);
+}
+
+// The cheap part of both tests on its own: true when the reference certainly finds no hit
+// (sphere behind the origin or farther from the line than r by more than every error; plane
+// numerator and denominator certainly of opposite signs).  About 15 operations, no
+// division, no square root, no branch: the filter the object loops run over every
+// primitive before the full test is spent on the few that survive.
+__device__ __forceinline__ bool certain_miss(const FGeomS& g, const RayF& r) {
+    if (g.r2 < 0.0f) {  // wave-uniform
+        const float denom = dot(r.d, g.q);
+        const float num = dot(g.p - r.o, g.q);
+        const float en = __builtin_fmaf(6.0f, g.cerr, r.en_ray);
+        return (num < -en && denom > r.eden) || (num > en && denom < -r.eden);
+    }
+    const F3 L = g.p - r.o;
+    const float tca = dot(L, r.d);
+    const F3 P = madd(L, r.d, -tca);
+    const float d2 = dot(P, P);
+    return tca < -r.etb || __builtin_fmaf(-2.01f, g.r2, d2) > r.far2;
+}
+
+// Per-lane copy of a primitive record (the index differs from lane to lane).
+__device__ __forceinline__ FGeomS gather_fgeom(const FGeom* tab, int i) {
+    const FGeom* r = tab + i;
+    FGeomS g;
+    g.p = f3(r->p[0], r->p[1], r->p[2]);
+    g.r2 = r->r2;
+    g.q = f3(r->q[0], r->q[1], r->q[2]);
+    g.transparency = r->transparency;
+    g.cerr = r->cerr;
+    return g;
+}
+
+// Pass 1 of an object loop: run the certain-miss filter over ALL primitives (wave-uniform
+// index, record in SGPRs, prefetched one ahead) and keep, per lane, how many survived and
+// the indices of the first two, in container order.  `skip` is a per-lane index that is
+// treated as a certain miss (the plane a ray was spawned on / the object a feeler starts on).
+struct Survivors {
+    int cnt, c0, c1;
+};
+__device__ __forceinline__ Survivors filter_prims(cfdata_t geom, int n, const RayF& r, int skip, bool active) {
+    Survivors s;
+    s.cnt = 0;
+    s.c0 = 0;
+    s.c1 = 0;
+    FGeomS gn = load_fgeom(geom, 0);
+    for (int i = 0; i < n; ++i) {
+        const FGeomS g = gn;
+        gn = load_fgeom(geom, (i + 1 < n) ? i + 1 : i);
+        const bool keep = active & (i != skip) & !certain_miss(g, r);
+        s.c0 = (keep & (s.cnt == 0)) ? i : s.c0;
+        s.c1 = (keep & (s.cnt == 1)) ? i : s.c1;
+        s.cnt += keep ? 1 : 0;
+    }
+    return s;
+}
+
+// Full certified float test of a per-lane record.
+__device__ __forceinline__ int test_prim_lane(const FGeomS& g, const RayF& r, float U, float& t, float& te) {
+    float ts, tes, tp, tep;
+    const int ss = sphere_test(g, r, U, ts, tes);
+    const int sp = plane_test(g, r, U, tp, tep);
+    const bool pl = g.r2 < 0.0f;
+    t = pl ? tp : ts;
+    te = pl ? tep : tes;
+    return pl ? sp : ss;
 }
 
 // The same two tests on the double ray: for the rare float test that could not be
@@ -389,28 +440,42 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void whitted_fast_kernel(FArgs
         // candidate by more than both error bounds ----
         int cur = -1;
         float best_t = __builtin_inff(), best_e = 0.0f, second_lo = __builtin_inff();
-        for (int i = 0; i < a.n_prims; ++i) {
-            const FGeomS g = load_fgeom(geom, i);
+        // Pass 1: certain-miss filter over all primitives.  Pass 2: the full certified test
+        // on each lane's own survivors (almost always none or one).
+        const Survivors sv = filter_prims(geom, a.n_prims, rf, self_plane, true);
+        auto consider = [&](int i, bool on) {
+            if (!__any(on)) return;
+            const FGeomS g = gather_fgeom(a.geom, on ? i : 0);
             float t, te;
-            int st = test_prim(g, rf, U, t, te);
-            if (i == self_plane) st = kMiss;
-            if (st >= kUnsure) {
-                // repeat this one test in double
-                double t_d;
-                st = test_prim_d(a.geom64 + i, ray, V, t_d, te);
-                t = (float)t_d;
-                te += U * t;
-                if (st >= kUnsure) { bad = true; if (!why) why = 6 + (st >> 2); }
-            }
-            if (st == kHit) {
-                if (t < best_t) {
-                    second_lo = __builtin_fminf(second_lo, best_t - best_e);
-                    best_t = t;
-                    best_e = te;
-                    cur = i;
-                } else {
-                    second_lo = __builtin_fminf(second_lo, t - te);
+            int st = test_prim_lane(g, rf, U, t, te);
+            st = on ? st : kMiss;
+            if (__any(st >= kUnsure)) {
+                if (st >= kUnsure) {
+                    // repeat this one test in double
+                    double t_d;
+                    st = test_prim_d(a.geom64 + i, ray, V, t_d, te);
+                    t = (float)t_d;
+                    te += U * t;
+                    if (st >= kUnsure) { bad = true; if (!why) why = 6 + (st >> 2); }
                 }
+            }
+            // keep the smallest t and the lowest possible t of everything else
+            const bool hit = st == kHit;
+            const bool better = hit & (t < best_t);
+            const float other_lo = better ? (best_t - best_e) : (hit ? (t - te) : __builtin_inff());
+            second_lo = __builtin_fminf(second_lo, other_lo);
+            best_t = better ? t : best_t;
+            best_e = better ? te : best_e;
+            cur = better ? i : cur;
+        };
+        consider(sv.c0, sv.cnt > 0);
+        consider(sv.c1, sv.cnt > 1);
+        if (__any(sv.cnt > 2)) {
+            // more than two survivors in some lane: those lanes walk the rest of the list
+            for (int i = 0; i < a.n_prims; ++i) {
+                const FGeomS g = load_fgeom(geom, i);
+                const bool on = (sv.cnt > 2) & (i > sv.c1) & (i != self_plane) & !certain_miss(g, rf);
+                consider(i, on);
             }
         }
         if (!(second_lo > best_t + best_e) && cur >= 0) { bad = true; if (!why) why = 2; }
@@ -500,12 +565,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void whitted_fast_kernel(FArgs
                     prepare_ray(fr, U, a.scene_p1max);
                     float occl = 1.0f;
                     bool open = !bad;
-                    for (int oi = 0; oi < a.n_prims; ++oi) {
-                        if (!__any(open)) break;
-                        if (open && oi != cur) {
-                            const FGeomS g = load_fgeom(geom, oi);
-                            float p, pe;
-                            int st = test_prim(g, fr, U, p, pe);
+                    // first occluder in container order (src/objects.h:35-47): filter, then the
+                    // full test on each lane's survivors in order until one is a certified hit
+                    const Survivors fs = filter_prims(geom, a.n_prims, fr, cur, open);
+                    auto occluder = [&](int oi, bool on) {
+                        on = on & open;
+                        if (!__any(on)) return;
+                        const FGeomS g = gather_fgeom(a.geom, on ? oi : 0);
+                        float p, pe;
+                        int st = test_prim_lane(g, fr, U, p, pe);
+                        st = on ? st : kMiss;
+                        if (__any(st >= kUnsure)) {
                             if (st >= kUnsure) {
                                 // repeat in double with the double hit point and light
                                 const DLight* ld = a.lights64 + li;
@@ -519,25 +589,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void whitted_fast_kernel(FArgs
                                 double p_d;
                                 st = test_prim_d(a.geom64 + oi, frd, V, p_d, pe);
                                 p = (float)p_d;
+                                if (st >= kUnsure) { bad = true; if (!why) why = 10 + (st >> 2); open = false; }
                             }
-                            if (st >= kUnsure) {
-                                bad = true;
-                                if (!why) why = 10 + (st >> 2);
-                                open = false;
-                            } else if (st == kHit) {
-                                // first occluder in container order (src/objects.h:40-46); colour only
-                                F3 no;
-                                if (g.r2 < 0.0f) {
-                                    no = g.q;
-                                } else {
-                                    const F3 hv = madd(ipf, fr.d, p) - g.p;
-                                    no = hv * rsq(dot(hv, hv));
-                                }
-                                const float facing = -dot(no, fr.d);
-                                const float fres = (1.0f - facing) * (1.0f - 0.1f);   // mix(x, 0, .1f)
-                                occl = (1.0f - fres) * g.transparency;
-                                open = false;
-                            }
+                        }
+                        // occlusion factor of a hit (src/objects.h:40-46); colour only
+                        const F3 hv = madd(ipf, fr.d, p) - g.p;
+                        const F3 ns = hv * rsq(__builtin_fmaxf(dot(hv, hv), 1.0e-30f));
+                        const bool pl = g.r2 < 0.0f;
+                        const F3 no = f3(pl ? g.q.x : ns.x, pl ? g.q.y : ns.y, pl ? g.q.z : ns.z);
+                        const float facing = -dot(no, fr.d);
+                        const float fres = (1.0f - facing) * (1.0f - 0.1f);   // mix(x, 0, .1f)
+                        const bool hit = st == kHit;
+                        occl = hit ? (1.0f - fres) * g.transparency : occl;
+                        open = open & !hit;
+                    };
+                    occluder(fs.c0, fs.cnt > 0);
+                    occluder(fs.c1, fs.cnt > 1);
+                    if (__any(open & (fs.cnt > 2))) {
+                        for (int oi = 0; oi < a.n_prims; ++oi) {
+                            const FGeomS g = load_fgeom(geom, oi);
+                            const bool on = open & (fs.cnt > 2) & (oi > fs.c1) & (oi != cur) & !certain_miss(g, fr);
+                            occluder(oi, on);
                         }
                     }
                     // diffuse term (src/objects.h:50-60); n and the light direction are unit
