@@ -24,6 +24,7 @@ struct DevBuf {
 
 struct rt_ctx {
     int device = 0;
+    int n_cus = 256;
     std::string err;
     rt::DGeom* d_geom = nullptr;
     rt::DMat* d_mat = nullptr;
@@ -36,13 +37,8 @@ struct rt_ctx {
     rt::FLight* f_lights = nullptr;
     float scene_p1max = 0.0f;
     float guard = 1.0f;
-    // queue of pixels the single-precision pass hands to the double-precision kernel:
-    // two counters used alternately (the queue pass of one render zeroes the counter of
-    // the next), statistics {requeued pixels, fast renders}
-    DevBuf queue;
-    uint32_t* d_qcount = nullptr;           // [2]
+    // statistics of the fast pass: {pixels re-evaluated exactly, fast renders}
     unsigned long long* d_stats = nullptr;  // [2]
-    unsigned parity = 0;
     // grow-only device staging for rt_render's host outputs
     DevBuf bgr, hit_id, hit_mask, spawn_mask, counters, dbg_in, dbg_t, dbg_hit, dbg_unit;
     hipStream_t stream = nullptr;
@@ -162,11 +158,10 @@ int rt_create(int32_t device_id, rt_ctx** out) {
     rt_ctx* ctx = new (std::nothrow) rt_ctx();
     if (!ctx) return fail(nullptr, RT_ERR_NOMEM, "rt_create: out of host memory");
     ctx->device = device_id;
+    ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_qcount), 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_stats), 2 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ctx->d_qcount, 0, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(ctx->d_stats, 0, 2 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         rt_destroy(ctx);
@@ -189,8 +184,6 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->f_geom) (void)hipFree(ctx->f_geom);
     if (ctx->f_mat) (void)hipFree(ctx->f_mat);
     if (ctx->f_lights) (void)hipFree(ctx->f_lights);
-    if (ctx->queue.ptr) (void)hipFree(ctx->queue.ptr);
-    if (ctx->d_qcount) (void)hipFree(ctx->d_qcount);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -243,7 +236,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
     }
     // single-precision copies, with the rounding error of each position (2^-24 |p|_1)
     const float kU = 6.0e-8f;
-    std::vector<rt::FGeom> fgeom(n_prims);
+    std::vector<rt::FGeom> fgeom(n_prims + 1);
     std::vector<rt::FMat> fmat(n_prims);
     std::vector<rt::FLight> flt(n_lights > 0 ? n_lights : 1);
     float p1max = 0.0f;
@@ -255,23 +248,31 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         std::memset(&m, 0, sizeof m);
         double p1 = 0.0;
         for (int c = 0; c < 3; ++c) {
-            g.p[c] = static_cast<float>(s.p[c]);
-            g.q[c] = (s.type == RT_PRIM_PLANE) ? static_cast<float>(s.q[c]) : 0.0f;
             m.kd[c] = static_cast<float>(s.kd[c]);
             p1 += std::fabs(s.p[c]);
         }
-        g.r2 = (s.type == RT_PRIM_PLANE) ? -1.0f : static_cast<float>(s.q[0] * s.q[0]);
-        g.transparency = static_cast<float>(s.transparency);
-        g.cerr = static_cast<float>(p1) * kU;
-        g.radius = (s.type == RT_PRIM_SPHERE) ? static_cast<float>(s.q[0]) : 0.0f;
-        // a plane's infinite extent is not part of the far-miss radius; spheres are
-        if (s.type == RT_PRIM_SPHERE && static_cast<float>(p1) * 1.0001f > p1max) p1max = static_cast<float>(p1) * 1.0001f;
+        if (s.type == RT_PRIM_PLANE) {
+            // h = origin . normal; herr covers the rounding of h to float, of the normal
+            // (through |origin|) and of the double evaluation below
+            const double hd = s.p[0] * s.q[0] + s.p[1] * s.q[1] + s.p[2] * s.q[2];
+            for (int c = 0; c < 3; ++c) g.v[c] = static_cast<float>(s.q[c]);
+            g.v[3] = -1.0f;
+            g.v[4] = static_cast<float>(hd);
+            g.v[5] = kU * (static_cast<float>(std::fabs(hd)) + static_cast<float>(p1)) * 1.01f;
+        } else {
+            for (int c = 0; c < 3; ++c) g.v[c] = static_cast<float>(s.p[c]);
+            g.v[3] = static_cast<float>(s.q[0] * s.q[0]);
+            g.v[4] = static_cast<float>(p1) * kU;
+            if (static_cast<float>(p1) * 1.0001f > p1max) p1max = static_cast<float>(p1) * 1.0001f;
+        }
+        g.v[6] = static_cast<float>(s.transparency);
         m.reflectivity = static_cast<float>(s.reflectivity);
         m.transparency = static_cast<float>(s.transparency);
         m.ri = static_cast<float>(s.refraction_index);
         m.inv_ri = static_cast<float>(1.0 / s.refraction_index);
         m.ambient = static_cast<float>(s.ambient_intensity);
     }
+    fgeom[n_prims] = fgeom[n_prims - 1];   // prefetch pad
     for (int i = 0; i < n_lights; ++i) {
         std::memset(&flt[i], 0, sizeof flt[i]);
         double p1 = 0.0;
@@ -333,17 +334,14 @@ static int render_device_impl(rt_ctx* ctx, const rt_params* p, void* stream, uin
         RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, st));
         return RT_OK;
     }
-    // single-precision pass, then the double-precision kernel on what it could not certify
-    const size_t px = static_cast<size_t>(a.rows) * a.width;
-    if (px == 0) return RT_OK;
-    if ((rc = reserve(ctx, ctx->queue, px * sizeof(uint32_t))) != RT_OK) return rc;
+    // fast pass; the pixels it cannot certify are evaluated exactly inside the same kernel
+    if (a.rows == 0) return RT_OK;
     rt::FArgs f;
     std::memset(&f, 0, sizeof f);
     f.geom = ctx->f_geom; f.mat = ctx->f_mat; f.lights = ctx->f_lights;
     f.geom64 = ctx->d_geom; f.mat64 = ctx->d_mat; f.lights64 = ctx->d_lights;
     f.bgr = d_bgr; f.hit_id = d_hit_id; f.hit_mask = d_hit_mask; f.spawn_mask = d_spawn_mask;
-    f.queue = static_cast<uint32_t*>(ctx->queue.ptr);
-    f.queue_count = ctx->d_qcount + (ctx->parity & 1u);
+    f.stats = ctx->d_stats;
     f.reason = d_reason;
     f.n_prims = a.n_prims; f.n_lights = a.n_lights;
     f.width = a.width; f.height = a.height; f.max_depth = a.max_depth;
@@ -353,16 +351,13 @@ static int render_device_impl(rt_ctx* ctx, const rt_params* p, void* stream, uin
     for (int i = 0; i < 3; ++i) f.bgr_c[i] = static_cast<float>(a.bgr_c[i]);
     for (int i = 1; i <= RT_MAX_DEPTH; ++i) f.inv_depth[i] = static_cast<float>(a.inv_depth[i]);
     f.scene_p1max = ctx->scene_p1max;
+    f.max_blocks = 1 << 30;   // one wave per tile: the hardware dispatcher balances the load
     f.guard = ctx->guard;
-    a.queue = f.queue;
-    a.queue_count = f.queue_count;
-    a.queue_count_next = ctx->d_qcount + ((ctx->parity + 1u) & 1u);
-    a.stats = ctx->d_stats;
-    ctx->parity ^= 1u;
+    f.exact = a;
 #ifdef RT_STAMPS
     {
         static unsigned long long* d_st = nullptr;
-        const size_t waves = static_cast<size_t>((a.tiles_x + 3) / 4) * 4 * a.tiles_y;
+        const size_t waves = static_cast<size_t>(f.max_blocks) * 4;
         static size_t cap = 0;
         if (waves > cap) { if (d_st) (void)hipFree(d_st); (void)hipMalloc(reinterpret_cast<void**>(&d_st), waves * 16 * 8); cap = waves; }
         (void)hipMemsetAsync(d_st, 0, waves * 16 * 8, st);
@@ -382,7 +377,6 @@ static int render_device_impl(rt_ctx* ctx, const rt_params* p, void* stream, uin
     }
 #endif
     RT_HIP_TRY(ctx, rt::launch_whitted_fast(f, emit, st));
-    RT_HIP_TRY(ctx, rt::launch_whitted_queue(a, emit, st));
     return RT_OK;
 }
 

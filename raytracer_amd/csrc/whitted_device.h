@@ -46,7 +46,6 @@ static_assert(sizeof(DGeom) == 64 && sizeof(DMat) == 64 && sizeof(DLight) == 64,
 constexpr int kStackFields = 8;
 constexpr int kWavesPerBlock = 4;
 constexpr int kTile = 8;  // a wave renders an 8x8 pixel tile
-constexpr int kQueueBlocks = 1024;  // fixed grid of the queue pass (4 waves each)
 
 struct KArgs {
     const DGeom* geom;
@@ -66,21 +65,17 @@ struct KArgs {
     double pw, ph;             // pixel pitch (src/view_frustum.h:33-34)
     double bgr_c[3];
     double inv_depth[RT_MAX_DEPTH + 1];  // 1.0/depth for depth 1..max_depth-1
-    // Queue mode (exact re-evaluation of the pixels the single-precision pass could not
-    // decide): pixel numbers (strip row * width + x) and their count, both on the device.
-    const uint32_t* queue;
-    const uint32_t* queue_count;
-    uint32_t* queue_count_next;    // zeroed by the queue pass for the following render
-    unsigned long long* stats;     // [0] += pixels re-evaluated, [1] += renders
 };
 
-// ---- single-precision pass ---------------------------------------------------------
-// 48-byte primitive record: {p.xyz, r2 | -1 for a plane}, {q.xyz (plane normal),
-// transparency}, {cerr = 2^-24 * |p|_1, radius, 0, 0}; one s_load_dwordx8 + s_load_dwordx4.
+// ---- fast pass: float copies of the scene ------------------------------------------
+// 32-byte float primitive record, one s_load_dwordx8 (wave-uniform index) or two 16-byte
+// loads (per-lane index):
+//   sphere  {centre.xyz, r2        | cerr = 2^-24 |centre|_1, 0,    transparency, 0}
+//   plane   {normal.xyz, -1 (mark) | h = float(origin.normal), herr, transparency, 0}
+// with herr = 2^-24 |h| (+ the rounding of h itself).  The table carries one extra record
+// after the last primitive so that a one-ahead prefetch never leaves it.
 struct FGeom {
-    float p[3], r2;
-    float q[3], transparency;
-    float cerr, radius, pad[2];
+    float v[8];
 };
 // Material gathered per lane on a hit.
 struct FMat {
@@ -92,9 +87,10 @@ struct FLight {
     float pos[3], lerr;
     float ci[3], pad;
 };
-static_assert(sizeof(FGeom) == 48 && sizeof(FMat) == 32 && sizeof(FLight) == 32, "record size");
+static_assert(sizeof(FGeom) == 32 && sizeof(FMat) == 32 && sizeof(FLight) == 32, "record size");
 
-constexpr int kFastStackFields = 8;  // doubles: origin, direction, {weight, eo}, {ed, node}
+constexpr int kFastStackFields = 8;  // doubles: origin, direction, {weight, eo}, {ed, node | self}
+constexpr int kFastBlocksPerCU = 3;   // persistent grid: blocks (of 4 waves) per CU
 
 struct FArgs {
     const FGeom* geom;
@@ -107,8 +103,7 @@ struct FArgs {
     int32_t* hit_id;
     uint32_t* hit_mask;
     uint32_t* spawn_mask;
-    uint32_t* queue;           // pixels handed to the exact pass
-    uint32_t* queue_count;
+    unsigned long long* stats;  // [0] += pixels re-evaluated exactly, [1] += renders
     uint8_t* reason;           // diagnostics (nullable): why a pixel was handed over, 0 = certified
     unsigned long long* stamps; // diagnostic build only (nullable): per-segment cycle sums
     int32_t n_prims, n_lights;
@@ -118,13 +113,15 @@ struct FArgs {
     double pw64, ph64;         // pixel pitch (src/view_frustum.h:33-34)
     float bgr_c[3];
     float inv_depth[RT_MAX_DEPTH + 1];
-    float scene_p1max;         // max over primitives of |p|_1
+    int32_t max_blocks;        // cap on the grid size (blocks of 4 waves)
+    float scene_p1max;         // max over spheres of |centre|_1
     float guard;               // multiplier on every error bound (1 = as derived)
+    KArgs exact;               // arguments of the exact per-pixel walk (the fallback)
 };
 
+inline int fast_stack_entries(int max_depth) { return max_depth > 2 ? max_depth - 1 : 1; }
 inline size_t fast_stack_lds_bytes(int max_depth) {
-    int entries = max_depth - 2;
-    if (entries < 1) entries = 1;
+    const int entries = fast_stack_entries(max_depth);
     return (size_t)kWavesPerBlock * entries * kFastStackFields * 64 * sizeof(double);
 }
 
@@ -141,8 +138,6 @@ inline size_t stack_lds_bytes(int max_depth) {
 // `a` that are null are skipped), count = add event counts to a.counters.
 hipError_t launch_whitted(const KArgs& a, bool emit, bool count, hipStream_t stream);
 
-// Same kernel over the pixels listed in a.queue (count read on the device).
-hipError_t launch_whitted_queue(const KArgs& a, bool emit, hipStream_t stream);
 
 // Enqueue the collision-test hook (rt_debug_intersect).
 hipError_t launch_debug_intersect(const DGeom* geom, int prim, const double* rays, int n,

@@ -1,0 +1,354 @@
+// Exact (bit-faithful) evaluation of one pixel of the reference's Whitted trace, shared by
+// the exact kernels (whitted_kernels.hip) and by the fast pass (whitted_fast.hip), which
+// falls back to it for the pixels it cannot certify.
+//
+// One lane per pixel, one wave per 8x8 pixel tile.  The reference's recursion
+// (TraceRay, src/main.cc:19-113) becomes a per-lane depth-first walk over the ray tree
+// with an explicit stack in LDS: a hit node adds its own shaded colour, scaled by the
+// product of the reflection/refraction coefficients on the path from the root, pushes
+// its refraction child and goes on with its reflection child.  The combine of
+// src/main.cc:107-112 is linear in the children's colours, so this gives the same sum
+// with the additions in another order (colour only; every hit/miss/spawn decision is
+// taken on exactly the doubles the reference computes).
+//
+// All geometry is IEEE double with no multiply-add contraction (this file must be built
+// with -ffp-contract=off): add, mul, div and sqrt are correctly rounded on the device as
+// on the CPU, so intersection parameters, hit points, normals and child rays are the
+// same bits as in the reference, and so is every comparison made on them.
+//
+// Object loops run with a wave-uniform index: the 64-byte record is fetched with scalar
+// loads and broadcast from SGPRs, the plane/sphere branch is uniform.
+#pragma once
+
+#include "whitted_device.h"
+
+// Everything below must be compiled without multiply-add contraction.
+#pragma clang fp contract(off)
+
+namespace rt {
+namespace exact {
+
+
+// Scene records are only ever read; loading them through the constant address space
+// lets the compiler use scalar loads whenever the index is wave-uniform.
+#define RT_CONST __attribute__((address_space(4)))
+typedef const RT_CONST double* cdata_t;
+
+// Record `i` of a table of 64-byte records, read through the constant address space.
+__device__ __forceinline__ DGeom load_geom(cdata_t t, int i) {
+    const cdata_t r = t + (size_t)i * 8;
+    DGeom g;
+    g.p[0] = r[0]; g.p[1] = r[1]; g.p[2] = r[2];
+    g.q[0] = r[3]; g.q[1] = r[4]; g.q[2] = r[5];
+    g.r2 = r[6];
+    g.transparency = r[7];
+    return g;
+}
+__device__ __forceinline__ DLight load_light(cdata_t t, int i) {
+    const cdata_t r = t + (size_t)i * 8;
+    DLight l;
+    l.pos[0] = r[0]; l.pos[1] = r[1]; l.pos[2] = r[2];
+    l.ci[0] = r[3]; l.ci[1] = r[4]; l.ci[2] = r[5];
+    l.pad[0] = 0.0; l.pad[1] = 0.0;
+    return l;
+}
+
+struct V3 {
+    double x, y, z;
+};
+
+__device__ __forceinline__ V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+
+// gmtl::dot: sum over x,y,z in that order.  (gmtl starts the sum from 0; 0 + x differs
+// from x only in the sign of a zero result, which no later operation here can observe.)
+__device__ __forceinline__ double dot(V3 a, V3 b) {
+    double r = a.x * b.x;
+    r = r + a.y * b.y;
+    r = r + a.z * b.z;
+    return r;
+}
+__device__ __forceinline__ double len2(V3 a) { return dot(a, a); }
+// gmtl::normalize on a copy: length, then three divisions, skipped for a zero length.
+__device__ __forceinline__ V3 unit(V3 a) {
+    double len = __builtin_sqrt(len2(a));
+    if (len != 0.0) {
+        a.x = a.x / len;
+        a.y = a.y / len;
+        a.z = a.z / len;
+    }
+    return a;
+}
+
+// x*x*x with one rounding (the reference calls std::pow(x, 3), src/main.cc:101, which
+// the C library evaluates to within a rounding of the exact cube).
+__device__ __forceinline__ double cube_rn(double x) {
+    double p = x * x;
+    double pe = __builtin_fma(x, x, -p);
+    double q = p * x;
+    double qe = __builtin_fma(p, x, -q);
+    return q + (qe + pe * x);
+}
+
+// src/color.h:77-79 with amount = 0.1f: the double expression rounded to float.
+__device__ __forceinline__ double mix_tenth(double a, double b) {
+    const double amount = (double)0.1f;
+    float r = (float)((b * amount) + a * (1 - amount));
+    return (double)r;
+}
+
+// src/color.h:27-29; a NaN channel is defined as 0.
+__device__ __forceinline__ uint32_t to_u8(double v) {
+    double c = (v < 0.0) ? 0.0 : ((1.0 < v) ? 1.0 : v);
+    double s = c * 255;
+    if (!(s == s)) return 0;
+    return (uint32_t)(int)s;
+}
+
+// Plane::TestCollision (src/objects.h:91-102) / Sphere::TestCollision
+// (src/objects.h:124-138) of a broadcast primitive against this lane's ray.
+// `g` is wave-uniform, so the type branch is.
+__device__ __forceinline__ bool test_collision(const DGeom& g, V3 o, V3 d, double& t) {
+    if (__double2hiint(g.r2) < 0) {
+        V3 n = mk(g.q[0], g.q[1], g.q[2]);
+        double denom = dot(d, n);
+        if (__builtin_fabs(denom) > 1e-6) {
+            V3 diff = mk(g.p[0], g.p[1], g.p[2]) - o;
+            double tt = dot(diff, n) / denom;
+            if (tt > 0) {
+                t = tt;
+                return true;
+            }
+        }
+        return false;
+    }
+    V3 L = mk(g.p[0], g.p[1], g.p[2]) - o;
+    double tca = dot(L, d);
+    if (tca < 0) return false;
+    double d2 = dot(L, L) - tca * tca;
+    if (d2 > g.r2) return false;
+    double thc = __builtin_sqrt(g.r2 - d2);
+    double tt = tca - thc;
+    if (tt < 0) tt = tca + thc;
+    t = tt;
+    return true;
+}
+
+template <int MW>
+__device__ __forceinline__ void set_bit(uint32_t (&m)[MW > 0 ? MW : 1], uint32_t node) {
+#pragma unroll
+    for (int w = 0; w < MW; ++w) m[w] |= ((node >> 5) == (uint32_t)w) ? (1u << (node & 31)) : 0u;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
+    unsigned long long s = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
+
+// The whole walk of one pixel: lane-private except for the scalar scene loads.
+// (x, k) = column and strip row; `have` is false for lanes without a pixel.
+// MW = mask words kept per lane (0: neither hit_id nor masks are produced).
+template <int MW, bool COUNT>
+__device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const int k, bool have, double* stk,
+                                            uint32_t (&cnt)[8]) {
+    const cdata_t geom = (cdata_t)(const double*)a.geom;
+    const cdata_t lights = (cdata_t)(const double*)a.lights;
+    const bool inside = have;
+    const int band = k / a.band_rows;
+    const int y = (a.band_first + band * a.band_step) * a.band_rows + (k - band * a.band_rows);
+
+    const V3 bgr = mk(a.bgr_c[0], a.bgr_c[1], a.bgr_c[2]);
+
+    // Primary ray: src/main.cc:135-138, src/view_frustum.h:37-46, src/common.h:27-31.
+    V3 o = mk(0.0, 0.0, 0.0);
+    V3 d;
+    {
+        const int xi = x - a.width / 2;
+        const int yi = y - a.height / 2;
+        V3 p1 = mk((xi + 0.5) * a.pw, (yi + 0.5) * a.ph, 1.0);
+        d = unit(p1 - o);
+    }
+    double w = 1.0;
+    uint32_t node = 1;
+    int sp = 0;
+
+    double cr = 0.0, cg = 0.0, cb = 0.0;
+    int32_t first_hit = -1;
+    uint32_t hmask[MW > 0 ? MW : 1] = {0};
+    uint32_t smask[MW > 0 ? MW : 1] = {0};
+    uint32_t &c_rays = cnt[0], &c_phits = cnt[1], &c_hits = cnt[2], &c_sph = cnt[3], &c_pln = cnt[4],
+             &c_feel = cnt[5], &c_occ = cnt[6], &c_refr = cnt[7];
+
+    while (have) {
+        const int level = 32 - __builtin_clz(node);  // the reference's `depth`
+        if (MW > 0) set_bit<MW>(smask, node);
+        if (COUNT) ++c_rays;
+
+        // ---- nearest hit, src/main.cc:37-47 ----
+        int cur = -1;
+        double nearest = __builtin_inf();
+        for (int i = 0; i < a.n_prims; ++i) {
+            const DGeom g = load_geom(geom, i);
+            if (COUNT) { if (__double2hiint(g.r2) < 0) ++c_pln; else ++c_sph; }
+            double t;
+            if (test_collision(g, o, d, t)) {
+                if (t < nearest) {
+                    nearest = t;
+                    cur = i;
+                }
+            }
+        }
+        if (MW > 0 && level == 1) first_hit = cur;
+
+        bool next_in_regs = false;
+        if (cur < 0) {
+            // src/main.cc:49-53: the background, weighted by the path.
+            cr += w * bgr.x; cg += w * bgr.y; cb += w * bgr.z;
+        } else {
+            if (MW > 0) set_bit<MW>(hmask, node);
+            if (COUNT) { ++c_hits; if (level == 1) ++c_phits; }
+
+            // per-lane gather of the hit object's records
+            const DGeom* gsrc = a.geom + cur;
+            const DMat* msrc = a.mat + cur;
+            const double gr2 = gsrc->r2;
+            const V3 gp = mk(gsrc->p[0], gsrc->p[1], gsrc->p[2]);
+            const V3 gq = mk(gsrc->q[0], gsrc->q[1], gsrc->q[2]);
+            const V3 kd = mk(msrc->kd[0], msrc->kd[1], msrc->kd[2]);
+            const double m_refl = msrc->reflectivity;
+            const double m_tr = msrc->transparency;
+            double ri = msrc->refraction_index;
+            const double m_amb = msrc->ambient_intensity;
+
+            // src/main.cc:55-65
+            const V3 ip = o + d * nearest;
+            V3 n = unit((__double2hiint(gr2) < 0) ? gq : (ip - gp));
+            if (dot(n, d) > 0) {
+                n = -n;
+                ri = 1.0 / ri;
+            }
+
+            // ---- Object::Shade, src/objects.h:20-65 ----
+            double sr = 0.0, sg = 0.0, sb = 0.0;
+            for (int li = 0; li < a.n_lights; ++li) {
+                const DLight L = load_light(lights, li);
+                const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);  // feeler.dir
+                double occl = 1.0;
+                bool open = true;  // no occluder met yet
+                if (COUNT) ++c_feel;
+                for (int oi = 0; oi < a.n_prims; ++oi) {
+                    if (!__any(open)) break;
+                    if (open && oi != cur) {
+                        const DGeom g = load_geom(geom, oi);
+                        if (COUNT) { if (__double2hiint(g.r2) < 0) ++c_pln; else ++c_sph; }
+                        double p;
+                        if (test_collision(g, ip, fdir, p)) {
+                            // first occluder in container order, src/objects.h:40-46
+                            V3 hp = ip + fdir * p;
+                            V3 no = unit((__double2hiint(g.r2) < 0) ? mk(g.q[0], g.q[1], g.q[2])
+                                                                     : (hp - mk(g.p[0], g.p[1], g.p[2])));
+                            double facing = -dot(no, fdir);
+                            double fres = mix_tenth(1 - facing, 0.0);
+                            occl = (1 - fres) * g.transparency;
+                            open = false;
+                            if (COUNT) ++c_occ;
+                        }
+                    }
+                }
+                // src/objects.h:50-60 (light_dir is the same vector as feeler.dir)
+                double diff = __builtin_fabs(dot(n, fdir) /
+                                             (__builtin_sqrt(len2(n)) * __builtin_sqrt(len2(fdir))));
+                double tr_ = (kd.x * L.ci[0] * diff) * occl;
+                double tg_ = (kd.y * L.ci[1] * diff) * occl;
+                double tb_ = (kd.z * L.ci[2] * diff) * occl;
+                sr = sr + tr_; sr = (sr > 0.0) ? sr : 0.0;
+                sb = sb + tb_; sb = (sb > 0.0) ? sb : 0.0;
+                sg = sg + tg_; sg = (sg > 0.0) ? sg : 0.0;
+            }
+
+            // src/main.cc:70, 100-105
+            const V3 vt = d / __builtin_fabs(dot(d, n));
+            const double facing = -dot(n, d);
+            const double fresnel = mix_tenth(cube_rn(1 - facing), 1.0);
+            const double kt = (1 - fresnel) * m_tr;
+            const double kr = (1 - kt) * m_refl;
+            const double kdm = 1 - m_tr;
+            const double invd = a.inv_depth[level];
+
+            // own colour: surface*kd + (bgr*ambient)*kd*(1/depth), src/main.cc:111-112
+            cr += w * (sr * kdm + ((bgr.x * m_amb) * kdm) * invd);
+            cg += w * (sg * kdm + ((bgr.y * m_amb) * kdm) * invd);
+            cb += w * (sb * kdm + ((bgr.z * m_amb) * kdm) * invd);
+
+            // refraction test, src/main.cc:86-87
+            const double kk = (ri * ri) * len2(vt) - len2(vt + n);
+            const bool refr = kk > 0;
+            if (COUNT && refr) ++c_refr;
+            const double wr = w * kr, wt = w * kt;
+
+            if (level + 1 >= a.max_depth) {
+                // both children stop at the depth limit and return the background
+                double ws = refr ? (wr + wt) : wr;
+                cr += ws * bgr.x; cg += ws * bgr.y; cb += ws * bgr.z;
+            } else {
+                if (refr) {
+                    // src/main.cc:88-93; Ray's constructor normalises again (src/common.h:24)
+                    V3 td = (n + vt) * (1.0 / __builtin_sqrt(kk)) - n;
+                    td = unit(unit(td));
+                    V3 to = ip - n * 1e-4;
+                    double* e = stk + (size_t)sp * kStackFields * 64;
+                    e[0 * 64] = to.x; e[1 * 64] = to.y; e[2 * 64] = to.z;
+                    e[3 * 64] = td.x; e[4 * 64] = td.y; e[5 * 64] = td.z;
+                    e[6 * 64] = wt;
+                    e[7 * 64] = (double)(2 * node + 1);
+                    ++sp;
+                }
+                // src/main.cc:75-79
+                V3 rd = unit(unit(vt + n * 2.0));
+                o = ip + n * 1e-4;
+                d = rd;
+                w = wr;
+                node = 2 * node;
+                next_in_regs = true;
+            }
+        }
+
+        if (!next_in_regs) {
+            if (sp > 0) {
+                --sp;
+                const double* e = stk + (size_t)sp * kStackFields * 64;
+                o = mk(e[0 * 64], e[1 * 64], e[2 * 64]);
+                d = mk(e[3 * 64], e[4 * 64], e[5 * 64]);
+                w = e[6 * 64];
+                node = (uint32_t)e[7 * 64];
+            } else {
+                have = false;
+            }
+        }
+    }
+
+    if (inside) {
+        const size_t px = (size_t)k * a.width + x;
+        uint8_t* dst = a.bgr + 3 * px;  // src/screen.h:62-64
+        dst[0] = (uint8_t)to_u8(cb);
+        dst[1] = (uint8_t)to_u8(cg);
+        dst[2] = (uint8_t)to_u8(cr);
+        if (MW > 0) {
+            if (a.hit_id) a.hit_id[px] = first_hit;
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                if (a.hit_mask) a.hit_mask[px * MW + i] = hmask[i];
+                if (a.spawn_mask) a.spawn_mask[px * MW + i] = smask[i];
+            }
+        }
+    }
+}
+
+}  // namespace exact
+}  // namespace rt
