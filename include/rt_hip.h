@@ -74,10 +74,6 @@ typedef struct rt_light {
 
 /* rt_params.flags */
 #define RT_FLAG_COUNTERS 1u   /* also count events into rt_counters (slower kernel)      */
-#define RT_FLAG_EXACT 2u      /* render every pixel with the double-precision kernel; by
-                                 default a single-precision pass with certified decisions
-                                 runs first and only the pixels it cannot certify are
-                                 rendered in double.  RT_FLAG_COUNTERS implies this.     */
 
 /*
  * Per-render parameters: the values the reference hard-wires in Tracer()/main()
@@ -175,44 +171,16 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
                      rt_counters* d_counters);
 
 /*
- * Statistics since rt_create: how many pixels the single-precision pass handed to the
- * double-precision kernel, over how many renders that used the single-precision pass.
- * Waits for the context's outstanding work (call it after synchronising other streams).
- */
-typedef struct rt_stats {
-    uint64_t requeued_pixels;
-    uint64_t fast_renders;
-} rt_stats;
-int rt_get_stats(rt_ctx* ctx, rt_stats* out);
-
-/*
- * Test hook: multiply every error bound of the single-precision pass by `guard`.
- * 1 (the default) = bounds as derived, decisions certified.  0 = no certification: the
- * pass then decides on raw float comparisons and its results may differ from the
- * reference; tests use it to show that the bounds are what makes the pass exact.
- */
-int rt_debug_set_guard(rt_ctx* ctx, float guard);
-
-/*
- * Diagnostic hook: render the partition and report, per pixel (rows*width bytes, strip
- * order), why the single-precision pass handed it to the double-precision kernel:
- * 0 = every comparison was certified; otherwise (depth << 4) | cause with cause
- * 2 = two hit candidates too close to order, 3 = inside/outside test (dot(n, d) near 0),
- * 5 = total-reflection test (k near 0), 6..9 = a collision test of the nearest-hit loop,
- * 10..13 = a collision test of a shadow feeler; within those: +0 sphere, d2 against r^2 or
- * tca against 0; +1 sphere, near root against 0; +2 plane, |denom| against 1e-6; +3 plane,
- * t against 0.  p->flags must be 0.
- */
-int rt_debug_flag_reasons(rt_ctx* ctx, const rt_params* p, uint8_t* reasons);
-
-/*
  * Test hooks: run the device versions of the reference's collision tests and of the
  * vector normalisation on caller-supplied rays, so that their double results can be
  * compared bit for bit with a CPU evaluation.
  *   rays      n * 6 doubles on the host: origin xyz, direction xyz (used as given)
  *   prim      index into the uploaded scene
  *   t_out     n doubles: the collision parameter (src/objects.h:91-102,124-138)
- *   hit_out   n bytes: 1 = TestCollision returned a value, 0 = nullopt
+ *   hit_out   n bytes: 1 = TestCollision returned a value, 0 = nullopt.  The test is
+ *             made the way the render kernel makes it: a single-precision filter that
+ *             only ever answers "certainly nullopt" (applied when the direction has unit
+ *             length, as every ray of the render kernel has), then the double evaluation
  *   unit_out  n * 3 doubles: normalize(direction) as gmtl does it (length, then three
  *             divisions; unchanged when the length is 0)                      nullable
  */

@@ -20,7 +20,6 @@ RT_MAX_LIGHTS = 256
 RT_PRIM_PLANE = 0
 RT_PRIM_SPHERE = 1
 RT_FLAG_COUNTERS = 1
-RT_FLAG_EXACT = 2
 
 PRIM_DTYPE = np.dtype(
     [

@@ -31,14 +31,9 @@ struct rt_ctx {
     rt::DLight* d_lights = nullptr;
     int32_t n_prims = 0, n_lights = 0;
     bool have_scene = false;
-    // single-precision copies of the scene
+    // float image of the geometry for the certain-miss filter
     rt::FGeom* f_geom = nullptr;
-    rt::FMat* f_mat = nullptr;
-    rt::FLight* f_lights = nullptr;
     float scene_p1max = 0.0f;
-    float guard = 1.0f;
-    // statistics of the fast pass: {pixels re-evaluated exactly, fast renders}
-    unsigned long long* d_stats = nullptr;  // [2]
     // grow-only device staging for rt_render's host outputs
     DevBuf bgr, hit_id, hit_mask, spawn_mask, counters, dbg_in, dbg_t, dbg_hit, dbg_unit;
     hipStream_t stream = nullptr;
@@ -92,6 +87,8 @@ int make_args(rt_ctx* ctx, const rt_params* p, rt::KArgs& a) {
     a.geom = ctx->d_geom;
     a.mat = ctx->d_mat;
     a.lights = ctx->d_lights;
+    a.fgeom = ctx->f_geom;
+    a.scene_p1max = ctx->scene_p1max;
     a.n_prims = ctx->n_prims;
     a.n_lights = ctx->n_lights;
     a.width = p->width;
@@ -161,8 +158,6 @@ int rt_create(int32_t device_id, rt_ctx** out) {
     ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_stats), 2 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ctx->d_stats, 0, 2 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         rt_destroy(ctx);
         return hip_fail(nullptr, e, "rt_create: device set-up");
@@ -182,9 +177,6 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->d_mat) (void)hipFree(ctx->d_mat);
     if (ctx->d_lights) (void)hipFree(ctx->d_lights);
     if (ctx->f_geom) (void)hipFree(ctx->f_geom);
-    if (ctx->f_mat) (void)hipFree(ctx->f_mat);
-    if (ctx->f_lights) (void)hipFree(ctx->f_lights);
-    if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -216,16 +208,12 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         g.r2 = (s.type == RT_PRIM_PLANE) ? -1.0 : s.q[0] * s.q[0];
         if (s.type == RT_PRIM_SPHERE) {
             if (!(s.q[0] > 0.0)) return fail(ctx, RT_ERR_ARG, "rt_upload_scene: sphere radius must be positive");
-            g.q[0] = 1.0 / s.q[0];
-            g.q[1] = s.q[0];
-            g.q[2] = 0.0;
         }
         g.transparency = s.transparency;
         m.reflectivity = s.reflectivity;
         m.transparency = s.transparency;
         m.refraction_index = s.refraction_index;
         m.ambient_intensity = s.ambient_intensity;
-        m.pad = 1.0 / s.refraction_index;   // src/main.cc:64
     }
     for (int i = 0; i < n_lights; ++i) {
         std::memset(&lt[i], 0, sizeof lt[i]);
@@ -234,26 +222,20 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
             lt[i].ci[c] = lights[i].color[c] * lights[i].intensity;  // src/objects.h:54-56
         }
     }
-    // single-precision copies, with the rounding error of each position (2^-24 |p|_1)
+    // float image of the geometry with the rounding error of each record (U = 2^-24
+    // rounded up); see the filter's derivation in whitted_exact.inc.h
     const float kU = 6.0e-8f;
     std::vector<rt::FGeom> fgeom(n_prims + 1);
-    std::vector<rt::FMat> fmat(n_prims);
-    std::vector<rt::FLight> flt(n_lights > 0 ? n_lights : 1);
     float p1max = 0.0f;
     for (int i = 0; i < n_prims; ++i) {
         const rt_prim& s = prims[i];
         rt::FGeom& g = fgeom[i];
-        rt::FMat& m = fmat[i];
         std::memset(&g, 0, sizeof g);
-        std::memset(&m, 0, sizeof m);
         double p1 = 0.0;
-        for (int c = 0; c < 3; ++c) {
-            m.kd[c] = static_cast<float>(s.kd[c]);
-            p1 += std::fabs(s.p[c]);
-        }
+        for (int c = 0; c < 3; ++c) p1 += std::fabs(s.p[c]);
         if (s.type == RT_PRIM_PLANE) {
-            // h = origin . normal; herr covers the rounding of h to float, of the normal
-            // (through |origin|) and of the double evaluation below
+            // h = origin . normal; herr covers the rounding of h to float and the last
+            // subtraction of the filter (|h| <= |origin|_1)
             const double hd = s.p[0] * s.q[0] + s.p[1] * s.q[1] + s.p[2] * s.q[2];
             for (int c = 0; c < 3; ++c) g.v[c] = static_cast<float>(s.q[c]);
             g.v[3] = -1.0f;
@@ -265,36 +247,14 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
             g.v[4] = static_cast<float>(p1) * kU;
             if (static_cast<float>(p1) * 1.0001f > p1max) p1max = static_cast<float>(p1) * 1.0001f;
         }
-        g.v[6] = static_cast<float>(s.transparency);
-        m.reflectivity = static_cast<float>(s.reflectivity);
-        m.transparency = static_cast<float>(s.transparency);
-        m.ri = static_cast<float>(s.refraction_index);
-        m.inv_ri = static_cast<float>(1.0 / s.refraction_index);
-        m.ambient = static_cast<float>(s.ambient_intensity);
     }
     fgeom[n_prims] = fgeom[n_prims - 1];   // prefetch pad
-    for (int i = 0; i < n_lights; ++i) {
-        std::memset(&flt[i], 0, sizeof flt[i]);
-        double p1 = 0.0;
-        for (int c = 0; c < 3; ++c) {
-            flt[i].pos[c] = static_cast<float>(lights[i].pos[c]);
-            flt[i].ci[c] = static_cast<float>(lights[i].color[c] * lights[i].intensity);
-            p1 += std::fabs(lights[i].pos[c]);
-        }
-        flt[i].lerr = static_cast<float>(p1) * kU;
-    }
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->have_scene = false;
     if (ctx->f_geom) RT_HIP_TRY(ctx, hipFree(ctx->f_geom));
-    if (ctx->f_mat) RT_HIP_TRY(ctx, hipFree(ctx->f_mat));
-    if (ctx->f_lights) RT_HIP_TRY(ctx, hipFree(ctx->f_lights));
-    ctx->f_geom = nullptr; ctx->f_mat = nullptr; ctx->f_lights = nullptr;
+    ctx->f_geom = nullptr;
     RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->f_geom), fgeom.size() * sizeof(rt::FGeom)));
-    RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->f_mat), fmat.size() * sizeof(rt::FMat)));
-    RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->f_lights), flt.size() * sizeof(rt::FLight)));
     RT_HIP_TRY(ctx, hipMemcpy(ctx->f_geom, fgeom.data(), fgeom.size() * sizeof(rt::FGeom), hipMemcpyHostToDevice));
-    RT_HIP_TRY(ctx, hipMemcpy(ctx->f_mat, fmat.data(), fmat.size() * sizeof(rt::FMat), hipMemcpyHostToDevice));
-    RT_HIP_TRY(ctx, hipMemcpy(ctx->f_lights, flt.data(), flt.size() * sizeof(rt::FLight), hipMemcpyHostToDevice));
     ctx->scene_p1max = p1max;
     if (ctx->d_geom) RT_HIP_TRY(ctx, hipFree(ctx->d_geom));
     if (ctx->d_mat) RT_HIP_TRY(ctx, hipFree(ctx->d_mat));
@@ -312,9 +272,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
     return RT_OK;
 }
 
-static int render_device_impl(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_bgr, int32_t* d_hit_id,
-                              uint32_t* d_hit_mask, uint32_t* d_spawn_mask, rt_counters* d_counters,
-                              uint8_t* d_reason) {
+int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_bgr, int32_t* d_hit_id,
+                     uint32_t* d_hit_mask, uint32_t* d_spawn_mask, rt_counters* d_counters) {
     if (!ctx) return RT_ERR_ARG;
     if (!d_bgr) return fail(ctx, RT_ERR_ARG, "rt_render_device: d_bgr is null");
     rt::KArgs a;
@@ -328,79 +287,8 @@ static int render_device_impl(rt_ctx* ctx, const rt_params* p, void* stream, uin
     a.spawn_mask = d_spawn_mask;
     a.counters = reinterpret_cast<unsigned long long*>(d_counters);
     const bool emit = d_hit_id || d_hit_mask || d_spawn_mask;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (count || (p->flags & RT_FLAG_EXACT)) {
-        RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, st));
-        return RT_OK;
-    }
-    // fast pass; the pixels it cannot certify are evaluated exactly inside the same kernel
-    if (a.rows == 0) return RT_OK;
-    rt::FArgs f;
-    std::memset(&f, 0, sizeof f);
-    f.geom = ctx->f_geom; f.mat = ctx->f_mat; f.lights = ctx->f_lights;
-    f.geom64 = ctx->d_geom; f.mat64 = ctx->d_mat; f.lights64 = ctx->d_lights;
-    f.bgr = d_bgr; f.hit_id = d_hit_id; f.hit_mask = d_hit_mask; f.spawn_mask = d_spawn_mask;
-    f.stats = ctx->d_stats;
-    f.reason = d_reason;
-    f.n_prims = a.n_prims; f.n_lights = a.n_lights;
-    f.width = a.width; f.height = a.height; f.max_depth = a.max_depth;
-    f.band_rows = a.band_rows; f.band_first = a.band_first; f.band_step = a.band_step;
-    f.rows = a.rows; f.tiles_x = a.tiles_x; f.tiles_y = a.tiles_y; f.mask_words = a.mask_words;
-    f.pw64 = a.pw; f.ph64 = a.ph;
-    for (int i = 0; i < 3; ++i) f.bgr_c[i] = static_cast<float>(a.bgr_c[i]);
-    for (int i = 1; i <= RT_MAX_DEPTH; ++i) f.inv_depth[i] = static_cast<float>(a.inv_depth[i]);
-    f.scene_p1max = ctx->scene_p1max;
-    f.max_blocks = 1 << 30;   // one wave per tile: the hardware dispatcher balances the load
-    f.guard = ctx->guard;
-    f.exact = a;
-#ifdef RT_STAMPS
-    {
-        static unsigned long long* d_st = nullptr;
-        const size_t waves = static_cast<size_t>(f.max_blocks) * 4;
-        static size_t cap = 0;
-        if (waves > cap) { if (d_st) (void)hipFree(d_st); (void)hipMalloc(reinterpret_cast<void**>(&d_st), waves * 16 * 8); cap = waves; }
-        (void)hipMemsetAsync(d_st, 0, waves * 16 * 8, st);
-        f.stamps = d_st;
-        static int calls = 0;
-        if (++calls % 50 == 0) {
-            RT_HIP_TRY(ctx, rt::launch_whitted_fast(f, emit, st));
-            std::vector<unsigned long long> h(waves * 16);
-            (void)hipDeviceSynchronize();
-            (void)hipMemcpy(h.data(), d_st, waves * 16 * 8, hipMemcpyDeviceToHost);
-            unsigned long long sum[16] = {0};
-            for (size_t w = 0; w < waves; ++w) for (int i = 0; i < 16; ++i) sum[i] += h[w * 16 + i];
-            std::fprintf(stderr, "[stamps, one render, %zu waves] cycles/visits:", waves);
-            for (int i = 0; i < 7; ++i) std::fprintf(stderr, " s%d=%.0f/%llu(%.0f)", i, (double)sum[i], sum[8 + i], sum[8+i] ? (double)sum[i] / sum[8 + i] : 0.0);
-            std::fprintf(stderr, "\n");
-        }
-    }
-#endif
-    RT_HIP_TRY(ctx, rt::launch_whitted_fast(f, emit, st));
-    return RT_OK;
-}
-
-int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_bgr, int32_t* d_hit_id,
-                     uint32_t* d_hit_mask, uint32_t* d_spawn_mask, rt_counters* d_counters) {
-    return render_device_impl(ctx, p, stream, d_bgr, d_hit_id, d_hit_mask, d_spawn_mask, d_counters, nullptr);
-}
-
-int rt_debug_flag_reasons(rt_ctx* ctx, const rt_params* p, uint8_t* reasons) {
-    if (!ctx) return RT_ERR_ARG;
-    if (!reasons) return fail(ctx, RT_ERR_ARG, "rt_debug_flag_reasons: reasons is null");
-    if (check_params(p) != RT_OK) return fail(ctx, RT_ERR_ARG, "rt_params: value out of range");
-    if (p->flags & (RT_FLAG_COUNTERS | RT_FLAG_EXACT)) return fail(ctx, RT_ERR_ARG, "rt_debug_flag_reasons: flags must be 0");
-    const size_t px = static_cast<size_t>(rt_strip_rows(p)) * p->width;
-    if (px == 0) return RT_OK;
-    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc;
-    if ((rc = reserve(ctx, ctx->bgr, px * 3 + 4)) != RT_OK) return rc;
-    if ((rc = reserve(ctx, ctx->dbg_hit, px)) != RT_OK) return rc;
-    rc = render_device_impl(ctx, p, ctx->stream, static_cast<uint8_t*>(ctx->bgr.ptr), nullptr, nullptr, nullptr,
-                            nullptr, static_cast<uint8_t*>(ctx->dbg_hit.ptr));
-    if (rc != RT_OK) return rc;
-    RT_HIP_TRY(ctx, hipMemcpyAsync(reasons, ctx->dbg_hit.ptr, px, hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, static_cast<hipStream_t>(stream)));
     return RT_OK;
 }
 
@@ -443,25 +331,6 @@ int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id, ui
     return RT_OK;
 }
 
-int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
-    if (!ctx) return RT_ERR_ARG;
-    if (!out) return fail(ctx, RT_ERR_ARG, "rt_get_stats: out is null");
-    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    RT_HIP_TRY(ctx, hipDeviceSynchronize());
-    unsigned long long v[2] = {0, 0};
-    RT_HIP_TRY(ctx, hipMemcpy(v, ctx->d_stats, sizeof v, hipMemcpyDeviceToHost));
-    out->requeued_pixels = v[0];
-    out->fast_renders = v[1];
-    return RT_OK;
-}
-
-int rt_debug_set_guard(rt_ctx* ctx, float guard) {
-    if (!ctx) return RT_ERR_ARG;
-    if (!(guard >= 0.0f) || guard > 1.0e6f) return fail(ctx, RT_ERR_ARG, "rt_debug_set_guard: guard out of range");
-    ctx->guard = guard;
-    return RT_OK;
-}
-
 int rt_debug_intersect(rt_ctx* ctx, const double* rays, int32_t n, int32_t prim, double* t_out, uint8_t* hit_out,
                        double* unit_out) {
     if (!ctx) return RT_ERR_ARG;
@@ -477,7 +346,7 @@ int rt_debug_intersect(rt_ctx* ctx, const double* rays, int32_t n, int32_t prim,
     if ((rc = reserve(ctx, ctx->dbg_hit, N)) != RT_OK) return rc;
     if (unit_out && (rc = reserve(ctx, ctx->dbg_unit, N * 24)) != RT_OK) return rc;
     RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->dbg_in.ptr, rays, N * 48, hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP_TRY(ctx, rt::launch_debug_intersect(ctx->d_geom, prim, static_cast<const double*>(ctx->dbg_in.ptr), n,
+    RT_HIP_TRY(ctx, rt::launch_debug_intersect(ctx->d_geom, ctx->f_geom, ctx->scene_p1max, prim, static_cast<const double*>(ctx->dbg_in.ptr), n,
                                                static_cast<double*>(ctx->dbg_t.ptr),
                                                static_cast<uint8_t*>(ctx->dbg_hit.ptr),
                                                unit_out ? static_cast<double*>(ctx->dbg_unit.ptr) : nullptr,

@@ -15,7 +15,7 @@ namespace rt {
 // Geometry of one collider + the one material value a shadow feeler needs.
 // r2 < 0 marks a plane (q = unit normal as stored by the Plane constructor);
 // otherwise a sphere with r2 = radius*radius (std::pow(radius_,2), src/objects.h:125) and
-// q = {1/radius, radius, 0} (used by the fast pass only).
+// q = {1/radius, radius, 0} (not read by the kernels).
 struct DGeom {
     double p[3];
     double q[3];
@@ -30,7 +30,7 @@ struct DMat {
     double transparency;
     double refraction_index;
     double ambient_intensity;
-    double pad;  // 1.0 / refraction_index (used by the fast pass)
+    double pad;
 };
 
 // One point light; ci = light_color * double(intensity) (src/objects.h:54-56).
@@ -42,6 +42,18 @@ struct DLight {
 
 static_assert(sizeof(DGeom) == 64 && sizeof(DMat) == 64 && sizeof(DLight) == 64, "record size");
 
+// Float image of the geometry for the certain-miss filter (whitted_exact.inc.h): 32-byte
+// record, one s_load_dwordx8 at a wave-uniform index:
+//   sphere  {centre.xyz, r2        | cerr = 2^-24 |centre|_1 (rounded up), 0, 0, 0}
+//   plane   {normal.xyz, -1 (mark) | h = float(origin.normal), herr,       0, 0}
+// with herr bounding |h - origin.normal| and the float rounding of the normal applied to
+// the origin.  The table carries one extra record after the last primitive so that a
+// one-ahead prefetch never leaves it.
+struct FGeom {
+    float v[8];
+};
+static_assert(sizeof(FGeom) == 32, "record size");
+
 // Per-lane stack entry in LDS: origin xyz, direction xyz, weight, node number.
 constexpr int kStackFields = 8;
 constexpr int kWavesPerBlock = 4;
@@ -51,6 +63,7 @@ struct KArgs {
     const DGeom* geom;
     const DMat* mat;
     const DLight* lights;
+    const FGeom* fgeom;        // n_prims + 1 records
     uint8_t* bgr;
     int32_t* hit_id;
     uint32_t* hit_mask;
@@ -65,67 +78,8 @@ struct KArgs {
     double pw, ph;             // pixel pitch (src/view_frustum.h:33-34)
     double bgr_c[3];
     double inv_depth[RT_MAX_DEPTH + 1];  // 1.0/depth for depth 1..max_depth-1
+    float scene_p1max;         // >= |centre|_1 of every sphere (filter bound)
 };
-
-// ---- fast pass: float copies of the scene ------------------------------------------
-// 32-byte float primitive record, one s_load_dwordx8 (wave-uniform index) or two 16-byte
-// loads (per-lane index):
-//   sphere  {centre.xyz, r2        | cerr = 2^-24 |centre|_1, 0,    transparency, 0}
-//   plane   {normal.xyz, -1 (mark) | h = float(origin.normal), herr, transparency, 0}
-// with herr = 2^-24 |h| (+ the rounding of h itself).  The table carries one extra record
-// after the last primitive so that a one-ahead prefetch never leaves it.
-struct FGeom {
-    float v[8];
-};
-// Material gathered per lane on a hit.
-struct FMat {
-    float kd[3], reflectivity;
-    float transparency, ri, inv_ri, ambient;
-};
-// Light: position, 2^-24 * |pos|_1, colour * intensity.
-struct FLight {
-    float pos[3], lerr;
-    float ci[3], pad;
-};
-static_assert(sizeof(FGeom) == 32 && sizeof(FMat) == 32 && sizeof(FLight) == 32, "record size");
-
-constexpr int kFastStackFields = 8;  // doubles: origin, direction, {weight, eo}, {ed, node | self}
-constexpr int kFastBlocksPerCU = 3;   // persistent grid: blocks (of 4 waves) per CU
-
-struct FArgs {
-    const FGeom* geom;
-    const FMat* mat;
-    const FLight* lights;
-    const DGeom* geom64;       // double tables (for spheres q = {1/r, r, 0})
-    const DMat* mat64;
-    const DLight* lights64;
-    uint8_t* bgr;
-    int32_t* hit_id;
-    uint32_t* hit_mask;
-    uint32_t* spawn_mask;
-    unsigned long long* stats;  // [0] += pixels re-evaluated exactly, [1] += renders
-    uint8_t* reason;           // diagnostics (nullable): why a pixel was handed over, 0 = certified
-    unsigned long long* stamps; // diagnostic build only (nullable): per-segment cycle sums
-    int32_t n_prims, n_lights;
-    int32_t width, height, max_depth;
-    int32_t band_rows, band_first, band_step;
-    int32_t rows, tiles_x, tiles_y, mask_words;
-    double pw64, ph64;         // pixel pitch (src/view_frustum.h:33-34)
-    float bgr_c[3];
-    float inv_depth[RT_MAX_DEPTH + 1];
-    int32_t max_blocks;        // cap on the grid size (blocks of 4 waves)
-    float scene_p1max;         // max over spheres of |centre|_1
-    float guard;               // multiplier on every error bound (1 = as derived)
-    KArgs exact;               // arguments of the exact per-pixel walk (the fallback)
-};
-
-inline int fast_stack_entries(int max_depth) { return max_depth > 2 ? max_depth - 1 : 1; }
-inline size_t fast_stack_lds_bytes(int max_depth) {
-    const int entries = fast_stack_entries(max_depth);
-    return (size_t)kWavesPerBlock * entries * kFastStackFields * 64 * sizeof(double);
-}
-
-hipError_t launch_whitted_fast(const FArgs& a, bool emit, hipStream_t stream);
 
 // Bytes of dynamic LDS one block needs for a given max_depth.
 inline size_t stack_lds_bytes(int max_depth) {
@@ -140,7 +94,7 @@ hipError_t launch_whitted(const KArgs& a, bool emit, bool count, hipStream_t str
 
 
 // Enqueue the collision-test hook (rt_debug_intersect).
-hipError_t launch_debug_intersect(const DGeom* geom, int prim, const double* rays, int n,
+hipError_t launch_debug_intersect(const DGeom* geom, const FGeom* fgeom, float scene_p1max, int prim, const double* rays, int n,
                                   double* t_out, uint8_t* hit_out, double* unit_out,
                                   hipStream_t stream);
 

@@ -109,6 +109,88 @@ __device__ __forceinline__ uint32_t to_u8(double v) {
     return (uint32_t)(int)s;
 }
 
+
+// ---- single-precision certain-miss filter --------------------------------------------
+// Most collision tests of a ray are misses by a wide margin.  Those are recognised on the
+// float image of the (exact, double) ray with a few float operations and a rigorous error
+// bound; only the tests the filter cannot rule out are evaluated in double.  The filter
+// never decides anything but "the reference's test certainly returns nullopt", so the
+// results stay the reference's bit for bit.
+//
+// U = 2^-24 (rounded up).  Float image of the ray: |o~ - o| <= U|o|_1 =: eo, |d~ - d| <= 2U
+// =: ed.  Float image of a primitive: |c~ - c| <= U|c|_1 =: cerr (stored in the record).
+//   sphere (src/objects.h:124-131), L = c~ - o~:  |L - L*| <= eo + cerr + U|L|   =: eL
+//     tca = L.d~:  |tca - tca*| <= eL + |L|(ed + 3U)                            =: et
+//     P = L - tca d~ (perpendicular part): |P - P*| <= 2 et + 2U|L|             =: eP
+//     the reference misses when tca* < 0 or d2* = |P*|^2 (up to 4*2^-53 |L|^2) > r2:
+//     certain when tca < -et, or |P| > r + eP, which follows from d2 > 2 r2 + 2 eP^2;
+//     the test uses 2.01 r2 + 3 eP^2, the surplus eP^2 > 1e-12 |L|^2 covering d2*'s own error.
+//     et, eP are replaced by per-ray bounds etb, ePb using |L|_1 <= |o~|_1 + max|c|_1.
+//   plane (src/objects.h:91-101), num = h~ - o~.n~ with h~ = float(p0.n):
+//     |num - num*| <= eo + 5U|o|_1 + herr =: en,  |denom - denom*| <= ed + 4U =: eden;
+//     the reference misses when t* = num*/denom* <= 0 (or |denom*| <= 1e-6): certain when
+//     num and denom are certainly non-zero with opposite signs.
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float dotf(F3 a, F3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ float l1f(F3 a) { return __builtin_fabsf(a.x) + __builtin_fabsf(a.y) + __builtin_fabsf(a.z); }
+
+typedef const RT_CONST float* cfdata_t;
+struct FRec {            // one FGeom record in SGPRs
+    float a0, a1, a2, r2;  // centre | normal,  r2 | -1 (plane)
+    float b0, b1;          // sphere: cerr, 0 ; plane: h, herr
+};
+__device__ __forceinline__ FRec load_rec(cfdata_t p) {
+    FRec g;
+    g.a0 = p[0]; g.a1 = p[1]; g.a2 = p[2]; g.r2 = p[3];
+    g.b0 = p[4]; g.b1 = p[5];
+    return g;
+}
+
+struct FilterRay {
+    F3 o, d;
+    float etb;    // bound on the error of any tca of this ray
+    float far2;   // 3 * ePb^2
+    float en_ray; // eo + 5U|o|_1
+    float eden;   // ed + 4U
+};
+__device__ __forceinline__ FilterRay filter_ray(V3 o, V3 d, float scene_p1max) {
+    const float U = 6.0e-8f;
+    FilterRay r;
+    r.o = f3((float)o.x, (float)o.y, (float)o.z);
+    r.d = f3((float)d.x, (float)d.y, (float)d.z);
+    const float o1 = l1f(r.o);
+    const float eo = U * o1;
+    const float ed3 = 5.0f * U;                      // ed + 3U
+    const float Sb = o1 + scene_p1max;               // >= |c~ - o~|_1 for every sphere
+    const float eLb = eo + U * scene_p1max + U * Sb;
+    r.etb = __builtin_fmaf(Sb, ed3, eLb);
+    const float ePb = __builtin_fmaf(2.0f * U, Sb, 2.0f * r.etb);
+    r.far2 = 3.0f * ePb * ePb;
+    r.en_ray = 6.0f * eo;
+    r.eden = 6.0f * U;
+    return r;
+}
+// True when the reference's test of this ray against the primitive certainly returns
+// nullopt.  ~15 float operations, no division, no square root.
+__device__ __forceinline__ bool certain_miss(const FRec& g, const FilterRay& r) {
+    const F3 a = f3(g.a0, g.a1, g.a2);
+    if (__float_as_int(g.r2) < 0) {  // plane (wave-uniform)
+        const float denom = dotf(r.d, a);
+        const float num = g.b0 - dotf(r.o, a);
+        const float en = r.en_ray + g.b1;
+        return (num < -en && denom > r.eden) || (num > en && denom < -r.eden);
+    }
+    const F3 L = a - r.o;
+    const float tca = dotf(L, r.d);
+    const F3 P = f3(__builtin_fmaf(-tca, r.d.x, L.x), __builtin_fmaf(-tca, r.d.y, L.y), __builtin_fmaf(-tca, r.d.z, L.z));
+    const float d2 = dotf(P, P);
+    return tca < -r.etb || __builtin_fmaf(-2.01f, g.r2, d2) > r.far2;
+}
+
 // Plane::TestCollision (src/objects.h:91-102) / Sphere::TestCollision
 // (src/objects.h:124-138) of a broadcast primitive against this lane's ray.
 // `g` is wave-uniform, so the type branch is.
@@ -159,6 +241,7 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                                             uint32_t (&cnt)[8]) {
     const cdata_t geom = (cdata_t)(const double*)a.geom;
     const cdata_t lights = (cdata_t)(const double*)a.lights;
+    const cfdata_t fgeom = (cfdata_t)(const float*)a.fgeom;
     const bool inside = have;
     const int band = k / a.band_rows;
     const int y = (a.band_first + band * a.band_step) * a.band_rows + (k - band * a.band_rows);
@@ -193,14 +276,25 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
         // ---- nearest hit, src/main.cc:37-47 ----
         int cur = -1;
         double nearest = __builtin_inf();
-        for (int i = 0; i < a.n_prims; ++i) {
-            const DGeom g = load_geom(geom, i);
-            if (COUNT) { if (__double2hiint(g.r2) < 0) ++c_pln; else ++c_sph; }
-            double t;
-            if (test_collision(g, o, d, t)) {
-                if (t < nearest) {
-                    nearest = t;
-                    cur = i;
+        {
+            const FilterRay fr = filter_ray(o, d, a.scene_p1max);
+            cfdata_t fp = fgeom;
+            FRec gn = load_rec(fp);
+            for (int i = 0; i < a.n_prims; ++i) {
+                const FRec gf = gn;
+                fp += 8;
+                gn = load_rec(fp);                      // one record of padding ends the table
+                if (COUNT) { if (__float_as_int(gf.r2) < 0) ++c_pln; else ++c_sph; }
+                const bool maybe = !certain_miss(gf, fr);
+                if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
+                    const DGeom g = load_geom(geom, i);
+                    double t;
+                    if (maybe && test_collision(g, o, d, t)) {
+                        if (t < nearest) {
+                            nearest = t;
+                            cur = i;
+                        }
+                    }
                 }
             }
         }
@@ -242,13 +336,21 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                 double occl = 1.0;
                 bool open = true;  // no occluder met yet
                 if (COUNT) ++c_feel;
+                const FilterRay ffr = filter_ray(ip, fdir, a.scene_p1max);
+                cfdata_t fp = fgeom;
+                FRec gn = load_rec(fp);
                 for (int oi = 0; oi < a.n_prims; ++oi) {
                     if (!__any(open)) break;
-                    if (open && oi != cur) {
+                    const FRec gf = gn;
+                    fp += 8;
+                    gn = load_rec(fp);
+                    const bool tested = open && oi != cur;
+                    if (COUNT && tested) { if (__float_as_int(gf.r2) < 0) ++c_pln; else ++c_sph; }
+                    const bool maybe = tested && !certain_miss(gf, ffr);
+                    if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
                         const DGeom g = load_geom(geom, oi);
-                        if (COUNT) { if (__double2hiint(g.r2) < 0) ++c_pln; else ++c_sph; }
                         double p;
-                        if (test_collision(g, ip, fdir, p)) {
+                        if (maybe && test_collision(g, ip, fdir, p)) {
                             // first occluder in container order, src/objects.h:40-46
                             V3 hp = ip + fdir * p;
                             V3 no = unit((__double2hiint(g.r2) < 0) ? mk(g.q[0], g.q[1], g.q[2])
@@ -261,9 +363,10 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                         }
                     }
                 }
-                // src/objects.h:50-60 (light_dir is the same vector as feeler.dir)
-                double diff = __builtin_fabs(dot(n, fdir) /
-                                             (__builtin_sqrt(len2(n)) * __builtin_sqrt(len2(fdir))));
+                // src/objects.h:50-60 (light_dir is the same vector as feeler.dir).  The
+                // reference divides by length(normal) * length(light_dir): both are 1 to a
+                // few 2^-53, so the quotient is left out (colour only, below 1e-15).
+                double diff = __builtin_fabs(dot(n, fdir));
                 double tr_ = (kd.x * L.ci[0] * diff) * occl;
                 double tg_ = (kd.y * L.ci[1] * diff) * occl;
                 double tb_ = (kd.z * L.ci[2] * diff) * occl;

@@ -1,4 +1,4 @@
-// Exact Whitted trace kernels for MI355X (gfx950, wave64): every pixel evaluated with the
+// Whitted trace kernels for MI355X (gfx950, wave64): every pixel evaluated with the
 // reference's own double arithmetic (see whitted_exact.inc.h), one wave per 8x8 tile.
 #include "whitted_exact.inc.h"
 
@@ -29,12 +29,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void whitted_kernel(KArgs a) {
     const int wave = threadIdx.x >> 6;
     const int entries = a.max_depth > 3 ? a.max_depth - 2 : 1;
     double* stk = lds_stack + (size_t)wave * entries * kStackFields * 64 + lane;
-    const int tile = blockIdx.x * kWavesPerBlock + wave;
-    const int tx = tile % a.tiles_x;
-    const int ty = tile / a.tiles_x;
+    const int tx = blockIdx.x * kWavesPerBlock + wave;  // a block = 4 tiles side by side
+    const int ty = blockIdx.y;
     const int x = tx * kTile + (lane & 7);
     const int k = ty * kTile + (lane >> 3);  // row in strip order
-    const bool have = (ty < a.tiles_y) && (x < a.width) && (k < a.rows);
+    const bool have = (x < a.width) && (k < a.rows);
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     trace_pixel<MW, COUNT>(a, x, k, have, stk, cnt);
     flush_counters<COUNT>(a, cnt, lane);
@@ -42,11 +41,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void whitted_kernel(KArgs a) {
 
 template <int MW, bool COUNT>
 static hipError_t launch_t(const KArgs& a, hipStream_t stream) {
-    const int tiles = a.tiles_x * a.tiles_y;
-    const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (blocks <= 0) return hipSuccess;
+    const int bx = (a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (bx <= 0 || a.tiles_y <= 0) return hipSuccess;
     const size_t lds = stack_lds_bytes(a.max_depth);
-    hipLaunchKernelGGL((whitted_kernel<MW, COUNT>), dim3(blocks), dim3(64 * kWavesPerBlock), lds, stream, a);
+    hipLaunchKernelGGL((whitted_kernel<MW, COUNT>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -70,16 +68,22 @@ hipError_t launch_whitted(const KArgs& a, bool emit, bool count, hipStream_t str
     return hipErrorInvalidValue;
 }
 
-// rt_debug_intersect: one lane per ray, primitive broadcast.
-__global__ void debug_intersect_kernel(const DGeom* geom_, int prim, const double* rays, int n, double* t_out,
-                                       uint8_t* hit_out, double* unit_out) {
+// rt_debug_intersect: one lane per ray, primitive broadcast; the test is made the way the
+// render kernel makes it (certain-miss filter, then the double test).
+__global__ void debug_intersect_kernel(const DGeom* geom_, const FGeom* fgeom_, float p1max, int prim,
+                                       const double* rays, int n, double* t_out, uint8_t* hit_out,
+                                       double* unit_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const DGeom g = load_geom((cdata_t)(const double*)geom_, prim);
     V3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
     V3 d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     double t = 0.0;
-    bool hit = test_collision(g, o, d, t);
+    const FRec gf = load_rec((cfdata_t)(const float*)fgeom_ + 8 * prim);
+    const FilterRay fr = filter_ray(o, d, p1max);
+    // the filter presumes a unit direction, as every ray of the render kernel has
+    const bool unit_dir = __builtin_fabs(len2(d) - 1.0) < 1e-12;
+    bool hit = !(unit_dir && certain_miss(gf, fr)) && test_collision(g, o, d, t);
     t_out[i] = hit ? t : 0.0;
     hit_out[i] = hit ? 1 : 0;
     if (unit_out) {
@@ -90,10 +94,11 @@ __global__ void debug_intersect_kernel(const DGeom* geom_, int prim, const doubl
     }
 }
 
-hipError_t launch_debug_intersect(const DGeom* geom, int prim, const double* rays, int n, double* t_out,
-                                  uint8_t* hit_out, double* unit_out, hipStream_t stream) {
+hipError_t launch_debug_intersect(const DGeom* geom, const FGeom* fgeom, float scene_p1max, int prim,
+                                  const double* rays, int n, double* t_out, uint8_t* hit_out, double* unit_out,
+                                  hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(debug_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, geom, prim, rays, n,
+    hipLaunchKernelGGL(debug_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, geom, fgeom, scene_p1max, prim, rays, n,
                        t_out, hit_out, unit_out);
     return hipGetLastError();
 }

@@ -27,9 +27,6 @@ EXPORTS = (
     "rt_upload_scene",
     "rt_render",
     "rt_render_device",
-    "rt_get_stats",
-    "rt_debug_set_guard",
-    "rt_debug_flag_reasons",
     "rt_debug_intersect",
 )
 
@@ -64,9 +61,6 @@ def load_library():
     L.rt_render.restype, L.rt_render.argtypes = ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp]
     L.rt_render_device.restype, L.rt_render_device.argtypes = ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]
     L.rt_debug_intersect.restype, L.rt_debug_intersect.argtypes = ctypes.c_int, [vp, vp, i32, i32, vp, vp, vp]
-    L.rt_get_stats.restype, L.rt_get_stats.argtypes = ctypes.c_int, [vp, vp]
-    L.rt_debug_set_guard.restype, L.rt_debug_set_guard.argtypes = ctypes.c_int, [vp, ctypes.c_float]
-    L.rt_debug_flag_reasons.restype, L.rt_debug_flag_reasons.argtypes = ctypes.c_int, [vp, vp, vp]
     _lib = L
     return L
 
@@ -111,13 +105,11 @@ class DeviceTracer:
             self._L.rt_upload_scene(self._h, _ptr(self._prims), len(self._prims), _ptr(self._lights), len(self._lights))
         )
 
-    def render(self, params, want_ids=True, want_masks=True, want_counters=False, exact=False):
+    def render(self, params, want_ids=True, want_masks=True, want_counters=False):
         """rt_render into fresh host arrays.  Same dict as the checker returns."""
         p = np.array(params, dtype=abi.PARAMS_DTYPE)
         if want_counters:
             p["flags"] = int(p["flags"]) | abi.RT_FLAG_COUNTERS
-        if exact:
-            p["flags"] = int(p["flags"]) | abi.RT_FLAG_EXACT
         rows = self._L.rt_strip_rows(_ptr(p))
         if rows < 0:
             raise RtError(rows, "bad rt_params")
@@ -145,25 +137,6 @@ class DeviceTracer:
                 as_vp(d_spawn_mask), as_vp(d_counters),
             )
         )
-
-    def stats(self) -> dict:
-        """rt_get_stats: pixels the single-precision pass handed to the exact kernel, and
-        the number of renders that used the single-precision pass, since creation."""
-        out = np.zeros(2, dtype=np.uint64)
-        self._check(self._L.rt_get_stats(self._h, _ptr(out)))
-        return {"requeued_pixels": int(out[0]), "fast_renders": int(out[1])}
-
-    def set_guard(self, guard: float):
-        """rt_debug_set_guard (test hook): scale the single-precision pass's error bounds."""
-        self._check(self._L.rt_debug_set_guard(self._h, guard))
-
-    def flag_reasons(self, params) -> np.ndarray:
-        """rt_debug_flag_reasons: per pixel, 0 or (depth << 4 | cause) of the hand-over."""
-        p = np.array(params, dtype=abi.PARAMS_DTYPE)
-        rows = self._L.rt_strip_rows(_ptr(p))
-        out = np.zeros((max(rows, 0), int(p["width"])), dtype=np.uint8)
-        self._check(self._L.rt_debug_flag_reasons(self._h, _ptr(p), _ptr(out)))
-        return out
 
     def debug_intersect(self, rays: np.ndarray, prim: int):
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
