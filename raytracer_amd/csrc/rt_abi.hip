@@ -214,6 +214,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         m.transparency = s.transparency;
         m.refraction_index = s.refraction_index;
         m.ambient_intensity = s.ambient_intensity;
+        m.pad = 1.0 / s.refraction_index;  // src/main.cc:64, the same division done once
     }
     for (int i = 0; i < n_lights; ++i) {
         std::memset(&lt[i], 0, sizeof lt[i]);
@@ -225,7 +226,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
     // float image of the geometry with the rounding error of each record (U = 2^-24
     // rounded up); see the filter's derivation in whitted_exact.inc.h
     const float kU = 6.0e-8f;
-    std::vector<rt::FGeom> fgeom(n_prims + 1);
+    std::vector<rt::FGeom> fgeom((static_cast<size_t>(n_prims) + 3) / 4 * 4);
     float p1max = 0.0f;
     for (int i = 0; i < n_prims; ++i) {
         const rt_prim& s = prims[i];
@@ -248,7 +249,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
             if (static_cast<float>(p1) * 1.0001f > p1max) p1max = static_cast<float>(p1) * 1.0001f;
         }
     }
-    fgeom[n_prims] = fgeom[n_prims - 1];   // prefetch pad
+    for (size_t i = n_prims; i < fgeom.size(); ++i) fgeom[i] = fgeom[n_prims - 1];  // pad to whole groups of 4
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->have_scene = false;
     if (ctx->f_geom) RT_HIP_TRY(ctx, hipFree(ctx->f_geom));

@@ -30,7 +30,7 @@ struct DMat {
     double transparency;
     double refraction_index;
     double ambient_intensity;
-    double pad;
+    double pad;  // 1.0 / refraction_index
 };
 
 // One point light; ci = light_color * double(intensity) (src/objects.h:54-56).
@@ -47,8 +47,8 @@ static_assert(sizeof(DGeom) == 64 && sizeof(DMat) == 64 && sizeof(DLight) == 64,
 //   sphere  {centre.xyz, r2        | cerr = 2^-24 |centre|_1 (rounded up), 0, 0, 0}
 //   plane   {normal.xyz, -1 (mark) | h = float(origin.normal), herr,       0, 0}
 // with herr bounding |h - origin.normal| and the float rounding of the normal applied to
-// the origin.  The table carries one extra record after the last primitive so that a
-// one-ahead prefetch never leaves it.
+// the origin.  The table is padded to a multiple of four records (the kernels read it in
+// groups of four).
 struct FGeom {
     float v[8];
 };
@@ -63,7 +63,7 @@ struct KArgs {
     const DGeom* geom;
     const DMat* mat;
     const DLight* lights;
-    const FGeom* fgeom;        // n_prims + 1 records
+    const FGeom* fgeom;        // n_prims records rounded up to a multiple of 4
     uint8_t* bgr;
     int32_t* hit_id;
     uint32_t* hit_mask;

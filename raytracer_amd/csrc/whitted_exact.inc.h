@@ -1,6 +1,4 @@
-// Exact (bit-faithful) evaluation of one pixel of the reference's Whitted trace, shared by
-// the exact kernels (whitted_kernels.hip) and by the fast pass (whitted_fast.hip), which
-// falls back to it for the pixels it cannot certify.
+// Bit-faithful evaluation of one pixel of the reference's Whitted trace.
 //
 // One lane per pixel, one wave per 8x8 pixel tile.  The reference's recursion
 // (TraceRay, src/main.cc:19-113) becomes a per-lane depth-first walk over the ray tree
@@ -73,15 +71,104 @@ __device__ __forceinline__ double dot(V3 a, V3 b) {
     return r;
 }
 __device__ __forceinline__ double len2(V3 a) { return dot(a, a); }
-// gmtl::normalize on a copy: length, then three divisions, skipped for a zero length.
-__device__ __forceinline__ V3 unit(V3 a) {
-    double len = __builtin_sqrt(len2(a));
+
+// ---- correctly rounded sqrt and division without the range scaling -------------------
+// The compiler expands an IEEE double sqrt or division into an estimate (v_rsq / v_rcp),
+// Newton steps and a final correction by the exact residual, wrapped in a rescaling
+// (v_ldexp / v_div_scale / v_div_fixup) that only acts when an operand, the reciprocal or
+// the result leaves the normal range.  The helpers below are the same sequences without
+// the wrapping; the callers use them only where the wrapping would be the identity
+// (operands and results between 2^-760 and 2^760), so they return the same correctly
+// rounded bits, and fall back to the plain operators elsewhere.  What is gained: the
+// three divisions of a normalisation share one refined reciprocal.
+__device__ __forceinline__ double sqrt_mid(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double s0 = x * y;
+    const double h0 = y * 0.5;
+    const double r0 = __builtin_fma(-h0, s0, 0.5);
+    const double s1 = __builtin_fma(s0, r0, s0);
+    const double h1 = __builtin_fma(h0, r0, h0);
+    const double d0 = __builtin_fma(-s1, s1, x);
+    const double s2 = __builtin_fma(d0, h1, s1);
+    const double d1 = __builtin_fma(-s2, s2, x);
+    return __builtin_fma(d1, h1, s2);
+}
+__device__ __forceinline__ double rcp_refined(double s) {
+    double y = __builtin_amdgcn_rcp(s);
+    double e = __builtin_fma(-s, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-s, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+// n / s given y = rcp_refined(s), s > 0.  The copysign only matters for n = -0.
+__device__ __forceinline__ double div_mid(double n, double s, double y) {
+    const double q = n * y;
+    const double r = __builtin_fma(-s, q, n);
+    return __builtin_copysign(__builtin_fma(r, y, q), n);
+}
+// True when every active lane of the wave has `ok`: the guards below branch on that, so
+// that the wave runs either the short sequences or the plain operators, never both.
+__device__ __forceinline__ bool all_lanes(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
+
+// A numerator the unscaled division handles: zero, or at least `tiny` in magnitude.
+__device__ __forceinline__ bool mid_num(double v, double tiny) { return (__builtin_fabs(v) >= tiny) | (v == 0.0); }
+__device__ __forceinline__ bool mid_vec(V3 a, double tiny) {
+    return (int)mid_num(a.x, tiny) & (int)mid_num(a.y, tiny) & (int)mid_num(a.z, tiny);
+}
+
+// gmtl::normalize with the plain operators: length, then three divisions, skipped for a
+// zero length.
+__device__ __forceinline__ V3 unit_plain(V3 a) {
+    const double len = __builtin_sqrt(len2(a));
     if (len != 0.0) {
         a.x = a.x / len;
         a.y = a.y / len;
         a.z = a.z / len;
     }
     return a;
+}
+// The same for 2^-760 <= l2 = len2(a) <= 2^760 and components that are zero or >= 2^-380:
+// then len is in [2^-380, 2^380], |a_i| <= len (1 + 2^-52), every quotient is normal.
+__device__ __forceinline__ V3 unit_mid(V3 a, double l2) {
+    const double len = sqrt_mid(l2);
+    const double y = rcp_refined(len);
+    return mk(div_mid(a.x, len, y), div_mid(a.y, len, y), div_mid(a.z, len, y));
+}
+__device__ __forceinline__ V3 unit(V3 a) {
+    const double l2 = len2(a);
+    if (all_lanes((l2 >= 0x1p-760) & (l2 <= 0x1p760) & mid_vec(a, 0x1p-380))) return unit_mid(a, l2);
+    return unit_plain(a);
+}
+// unit(unit(a)): a Ray's constructor normalises the direction it is given, which the
+// caller has normalised already (src/common.h:24).  One guard covers both passes: with
+// components zero or >= 2^-250 and l2 in [2^-500, 2^500] the first result has components
+// zero or >= 2^-500 and a squared length within a few 2^-52 of 1.
+__device__ __forceinline__ V3 unit2(V3 a) {
+    const double l2 = len2(a);
+    if (all_lanes((l2 >= 0x1p-500) & (l2 <= 0x1p500) & mid_vec(a, 0x1p-250))) {
+        const V3 u = unit_mid(a, l2);
+        return unit_mid(u, len2(u));
+    }
+    return unit_plain(unit_plain(a));
+}
+
+// a / s, component by component, for |a_i| <= 2 max(s, 1) (both callers guarantee it).
+__device__ __forceinline__ V3 div3(V3 a, double s) {
+    if (all_lanes((s >= 0x1p-380) & (s <= 0x1p380) & mid_vec(a, 0x1p-380))) {
+        const double y = rcp_refined(s);
+        return mk(div_mid(a.x, s, y), div_mid(a.y, s, y), div_mid(a.z, s, y));
+    }
+    return mk(a.x / s, a.y / s, a.z / s);
+}
+// 1.0 / sqrt(x), both operations correctly rounded (src/main.cc:88).
+__device__ __forceinline__ double inv_sqrt_2r(double x) {
+    if (all_lanes((x >= 0x1p-760) & (x <= 0x1p760))) {
+        const double sx = sqrt_mid(x);
+        const double y = rcp_refined(sx);
+        return __builtin_fma(__builtin_fma(-sx, y, 1.0), y, y);
+    }
+    return 1.0 / __builtin_sqrt(x);
 }
 
 // x*x*x with one rounding (the reference calls std::pow(x, 3), src/main.cc:101, which
@@ -182,7 +269,8 @@ __device__ __forceinline__ bool certain_miss(const FRec& g, const FilterRay& r) 
         const float denom = dotf(r.d, a);
         const float num = g.b0 - dotf(r.o, a);
         const float en = r.en_ray + g.b1;
-        return (num < -en && denom > r.eden) || (num > en && denom < -r.eden);
+        // both certainly non-zero, and of opposite signs (no short-circuit: three compares)
+        return (__builtin_fabsf(num) > en) & (__builtin_fabsf(denom) > r.eden) & (num * denom < 0.0f);
     }
     const F3 L = a - r.o;
     const float tca = dotf(L, r.d);
@@ -195,29 +283,83 @@ __device__ __forceinline__ bool certain_miss(const FRec& g, const FilterRay& r) 
 // (src/objects.h:124-138) of a broadcast primitive against this lane's ray.
 // `g` is wave-uniform, so the type branch is.
 __device__ __forceinline__ bool test_collision(const DGeom& g, V3 o, V3 d, double& t) {
+    // Written without early returns: the lanes that get here have passed the filter, so
+    // most of them hit, and a NaN or infinity computed on the others is never used.  The
+    // conditions are the reference's, negated the way its early returns negate them.
     if (__double2hiint(g.r2) < 0) {
-        V3 n = mk(g.q[0], g.q[1], g.q[2]);
-        double denom = dot(d, n);
-        if (__builtin_fabs(denom) > 1e-6) {
-            V3 diff = mk(g.p[0], g.p[1], g.p[2]) - o;
-            double tt = dot(diff, n) / denom;
-            if (tt > 0) {
-                t = tt;
-                return true;
-            }
-        }
-        return false;
+        const V3 n = mk(g.q[0], g.q[1], g.q[2]);
+        const double denom = dot(d, n);
+        const V3 diff = mk(g.p[0], g.p[1], g.p[2]) - o;
+        const double tt = dot(diff, n) / denom;
+        t = tt;
+        return (__builtin_fabs(denom) > 1e-6) & (tt > 0);
     }
-    V3 L = mk(g.p[0], g.p[1], g.p[2]) - o;
-    double tca = dot(L, d);
-    if (tca < 0) return false;
-    double d2 = dot(L, L) - tca * tca;
-    if (d2 > g.r2) return false;
-    double thc = __builtin_sqrt(g.r2 - d2);
-    double tt = tca - thc;
-    if (tt < 0) tt = tca + thc;
-    t = tt;
-    return true;
+    const V3 L = mk(g.p[0], g.p[1], g.p[2]) - o;
+    const double tca = dot(L, d);
+    const double d2 = dot(L, L) - tca * tca;
+    const bool ok = !(tca < 0) & !(d2 > g.r2);
+    if (ok) {
+        const double thc = __builtin_sqrt(g.r2 - d2);
+        const double t0 = tca - thc;
+        t = (t0 < 0) ? tca + thc : t0;
+    }
+    return ok;
+}
+
+// The object loops take the scene four records at a time: the float records of a group
+// are fetched up front (scalar loads at constant offsets from one pointer), each slot
+// costs a handful of scalar instructions, and the double record of a primitive is only
+// fetched when some lane's filter cannot rule it out.  `rem` < 4 limits a trailing group.
+constexpr int kGroup = 4;
+struct FGroup {
+    FRec r[kGroup];
+};
+__device__ __forceinline__ FGroup load_group(cfdata_t fp) {
+    FGroup g;
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) g.r[j] = load_rec(fp + 8 * j);  // the table is padded to whole groups
+    return g;
+}
+
+// Slot of the nearest-hit loop (src/main.cc:37-47).
+template <bool COUNT>
+__device__ __forceinline__ void near_slot(const FRec& gf, cdata_t gp, int j, int idx, bool valid, const FilterRay& fr,
+                                          V3 o, V3 d, double& nearest, int& cur, uint32_t& c_sph, uint32_t& c_pln) {
+    if (COUNT && valid) { if (__float_as_int(gf.r2) < 0) ++c_pln; else ++c_sph; }
+    const bool maybe = valid && !certain_miss(gf, fr);
+    if (maybe) {
+        __asm__ volatile("" ::: "memory");  // nothing of the double test is to run ahead of the branch
+        const DGeom g = load_geom(gp, j);
+        double t;
+        const bool closer = test_collision(g, o, d, t) && t < nearest;
+        nearest = closer ? t : nearest;
+        cur = closer ? idx : cur;
+    }
+}
+
+// Slot of a shadow feeler's loop (src/objects.h:31-47): the first occluder in container
+// order decides, the shaded object itself is skipped.
+template <bool COUNT>
+__device__ __forceinline__ void feeler_slot(const FRec& gf, cdata_t gp, int j, int idx, bool valid, const FilterRay& fr,
+                                            V3 ip, V3 fdir, int cur, bool& open, double& occl, uint32_t& c_sph,
+                                            uint32_t& c_pln, uint32_t& c_occ) {
+    const bool tested = valid && open && idx != cur;
+    if (COUNT && tested) { if (__float_as_int(gf.r2) < 0) ++c_pln; else ++c_sph; }
+    const bool maybe = tested && !certain_miss(gf, fr);
+    if (maybe) {
+        __asm__ volatile("" ::: "memory");
+        const DGeom g = load_geom(gp, j);
+        double p;
+        if (test_collision(g, ip, fdir, p)) {
+            V3 hp = ip + fdir * p;
+            V3 no = unit((__double2hiint(g.r2) < 0) ? mk(g.q[0], g.q[1], g.q[2]) : (hp - mk(g.p[0], g.p[1], g.p[2])));
+            double facing = -dot(no, fdir);
+            double fres = mix_tenth(1 - facing, 0.0);
+            occl = (1 - fres) * g.transparency;
+            open = false;
+            if (COUNT) ++c_occ;
+        }
+    }
 }
 
 template <int MW>
@@ -279,23 +421,20 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
         {
             const FilterRay fr = filter_ray(o, d, a.scene_p1max);
             cfdata_t fp = fgeom;
-            FRec gn = load_rec(fp);
-            for (int i = 0; i < a.n_prims; ++i) {
-                const FRec gf = gn;
-                fp += 8;
-                gn = load_rec(fp);                      // one record of padding ends the table
-                if (COUNT) { if (__float_as_int(gf.r2) < 0) ++c_pln; else ++c_sph; }
-                const bool maybe = !certain_miss(gf, fr);
-                if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
-                    const DGeom g = load_geom(geom, i);
-                    double t;
-                    if (maybe && test_collision(g, o, d, t)) {
-                        if (t < nearest) {
-                            nearest = t;
-                            cur = i;
-                        }
-                    }
-                }
+            cdata_t gp = geom;
+            int base = 0;
+            for (; base + kGroup <= a.n_prims; base += kGroup, fp += 8 * kGroup, gp += 8 * kGroup) {
+                const FGroup G = load_group(fp);
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j)
+                    near_slot<COUNT>(G.r[j], gp, j, base + j, true, fr, o, d, nearest, cur, c_sph, c_pln);
+            }
+            if (base < a.n_prims) {
+                const FGroup G = load_group(fp);
+                const int rem = a.n_prims - base;
+#pragma unroll
+                for (int j = 0; j < kGroup - 1; ++j)
+                    near_slot<COUNT>(G.r[j], gp, j, base + j, j < rem, fr, o, d, nearest, cur, c_sph, c_pln);
             }
         }
         if (MW > 0 && level == 1) first_hit = cur;
@@ -325,7 +464,7 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
             V3 n = unit((__double2hiint(gr2) < 0) ? gq : (ip - gp));
             if (dot(n, d) > 0) {
                 n = -n;
-                ri = 1.0 / ri;
+                ri = msrc->pad;  // 1.0 / refraction_index, src/main.cc:64
             }
 
             // ---- Object::Shade, src/objects.h:20-65 ----
@@ -338,30 +477,23 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                 if (COUNT) ++c_feel;
                 const FilterRay ffr = filter_ray(ip, fdir, a.scene_p1max);
                 cfdata_t fp = fgeom;
-                FRec gn = load_rec(fp);
-                for (int oi = 0; oi < a.n_prims; ++oi) {
+                cdata_t gp = geom;
+                int base = 0;
+                for (; base + kGroup <= a.n_prims; base += kGroup, fp += 8 * kGroup, gp += 8 * kGroup) {
                     if (!__any(open)) break;
-                    const FRec gf = gn;
-                    fp += 8;
-                    gn = load_rec(fp);
-                    const bool tested = open && oi != cur;
-                    if (COUNT && tested) { if (__float_as_int(gf.r2) < 0) ++c_pln; else ++c_sph; }
-                    const bool maybe = tested && !certain_miss(gf, ffr);
-                    if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
-                        const DGeom g = load_geom(geom, oi);
-                        double p;
-                        if (maybe && test_collision(g, ip, fdir, p)) {
-                            // first occluder in container order, src/objects.h:40-46
-                            V3 hp = ip + fdir * p;
-                            V3 no = unit((__double2hiint(g.r2) < 0) ? mk(g.q[0], g.q[1], g.q[2])
-                                                                     : (hp - mk(g.p[0], g.p[1], g.p[2])));
-                            double facing = -dot(no, fdir);
-                            double fres = mix_tenth(1 - facing, 0.0);
-                            occl = (1 - fres) * g.transparency;
-                            open = false;
-                            if (COUNT) ++c_occ;
-                        }
-                    }
+                    const FGroup G = load_group(fp);
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j)
+                        feeler_slot<COUNT>(G.r[j], gp, j, base + j, true, ffr, ip, fdir, cur, open, occl, c_sph, c_pln,
+                                           c_occ);
+                }
+                if (base < a.n_prims && __any(open)) {
+                    const FGroup G = load_group(fp);
+                    const int rem = a.n_prims - base;
+#pragma unroll
+                    for (int j = 0; j < kGroup - 1; ++j)
+                        feeler_slot<COUNT>(G.r[j], gp, j, base + j, j < rem, ffr, ip, fdir, cur, open, occl, c_sph,
+                                           c_pln, c_occ);
                 }
                 // src/objects.h:50-60 (light_dir is the same vector as feeler.dir).  The
                 // reference divides by length(normal) * length(light_dir): both are 1 to a
@@ -376,7 +508,7 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
             }
 
             // src/main.cc:70, 100-105
-            const V3 vt = d / __builtin_fabs(dot(d, n));
+            const V3 vt = div3(d, __builtin_fabs(dot(d, n)));
             const double facing = -dot(n, d);
             const double fresnel = mix_tenth(cube_rn(1 - facing), 1.0);
             const double kt = (1 - fresnel) * m_tr;
@@ -402,8 +534,8 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
             } else {
                 if (refr) {
                     // src/main.cc:88-93; Ray's constructor normalises again (src/common.h:24)
-                    V3 td = (n + vt) * (1.0 / __builtin_sqrt(kk)) - n;
-                    td = unit(unit(td));
+                    V3 td = (n + vt) * inv_sqrt_2r(kk) - n;
+                    td = unit2(td);
                     V3 to = ip - n * 1e-4;
                     double* e = stk + (size_t)sp * kStackFields * 64;
                     e[0 * 64] = to.x; e[1 * 64] = to.y; e[2 * 64] = to.z;
@@ -413,7 +545,7 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                     ++sp;
                 }
                 // src/main.cc:75-79
-                V3 rd = unit(unit(vt + n * 2.0));
+                V3 rd = unit2(vt + n * 2.0);
                 o = ip + n * 1e-4;
                 d = rd;
                 w = wr;

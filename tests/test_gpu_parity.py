@@ -32,6 +32,14 @@ def test_collision_and_normalize_bits(tracer):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     rays[:, 3:6] = d
     rays[: n // 10, 3:6] *= rng.uniform(1e-3, 1e3, (n // 10, 1))  # un-normalised directions too
+    # directions with zero, signed-zero, tiny, huge and denormal components: the device's
+    # normalisation leaves its short sequence for these and must still match bit for bit
+    special = np.array([
+        [0.0, 1.0, 0.0], [-0.0, 3.0, 4.0], [0.0, -0.0, -2.0], [1e-200, 1.0, 0.0], [1e-300, 1e-300, 0.0],
+        [0.0, 0.0, 0.0], [1e300, 1e300, 1.0], [1e-160, 1e-160, 1e-160], [5e-324, 1.0, 1.0],
+        [1e-120, 2e-120, -3e-120], [1e200, -1e200, 1e-200], [3e-310, 0.0, 0.0],
+    ])
+    rays[n // 10 : n // 10 + len(special), 3:6] = special
     for prim in range(len(prims)):
         t_d, h_d, u_d = tracer.debug_intersect(rays, prim)
         t_o, h_o, u_o = oracle_lib.intersect(prims, rays, prim)
