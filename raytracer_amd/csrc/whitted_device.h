@@ -81,11 +81,13 @@ struct KArgs {
     float scene_p1max;         // >= |centre|_1 of every sphere (filter bound)
 };
 
+// The walk keeps at most one pending refraction child per tree level 2..max_depth-1.
+// The bottom entry (pushed by the primary hit) lives in registers, the others in LDS:
+// 4 KB per wave and entry, which is what bounds the number of resident waves.
+__host__ __device__ inline int stack_lds_entries(int max_depth) { return max_depth > 3 ? max_depth - 3 : 0; }
 // Bytes of dynamic LDS one block needs for a given max_depth.
 inline size_t stack_lds_bytes(int max_depth) {
-    int entries = max_depth - 2;
-    if (entries < 1) entries = 1;
-    return (size_t)kWavesPerBlock * entries * kStackFields * 64 * sizeof(double);
+    return (size_t)kWavesPerBlock * stack_lds_entries(max_depth) * kStackFields * 64 * sizeof(double);
 }
 
 // Enqueue the render of one strip on `stream`.  emit = write hit_id/masks (pointers in

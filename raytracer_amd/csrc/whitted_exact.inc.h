@@ -402,6 +402,7 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
     double w = 1.0;
     uint32_t node = 1;
     int sp = 0;
+    double bottom[kStackFields] = {0, 0, 0, 0, 0, 0, 0, 0};  // stack entry 0, in registers
 
     double cr = 0.0, cg = 0.0, cb = 0.0;
     int32_t first_hit = -1;
@@ -537,11 +538,15 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                     V3 td = (n + vt) * inv_sqrt_2r(kk) - n;
                     td = unit2(td);
                     V3 to = ip - n * 1e-4;
-                    double* e = stk + (size_t)sp * kStackFields * 64;
-                    e[0 * 64] = to.x; e[1 * 64] = to.y; e[2 * 64] = to.z;
-                    e[3 * 64] = td.x; e[4 * 64] = td.y; e[5 * 64] = td.z;
-                    e[6 * 64] = wt;
-                    e[7 * 64] = (double)(2 * node + 1);
+                    const double ent[kStackFields] = {to.x, to.y, to.z, td.x, td.y, td.z, wt, (double)(2 * node + 1)};
+                    if (sp == 0) {
+#pragma unroll
+                        for (int f = 0; f < kStackFields; ++f) bottom[f] = ent[f];
+                    } else {
+                        double* e = stk + (size_t)(sp - 1) * kStackFields * 64;
+#pragma unroll
+                        for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
+                    }
                     ++sp;
                 }
                 // src/main.cc:75-79
@@ -557,11 +562,19 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
         if (!next_in_regs) {
             if (sp > 0) {
                 --sp;
-                const double* e = stk + (size_t)sp * kStackFields * 64;
-                o = mk(e[0 * 64], e[1 * 64], e[2 * 64]);
-                d = mk(e[3 * 64], e[4 * 64], e[5 * 64]);
-                w = e[6 * 64];
-                node = (uint32_t)e[7 * 64];
+                double ent[kStackFields];
+                if (sp == 0) {
+#pragma unroll
+                    for (int f = 0; f < kStackFields; ++f) ent[f] = bottom[f];
+                } else {
+                    const double* e = stk + (size_t)(sp - 1) * kStackFields * 64;
+#pragma unroll
+                    for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
+                }
+                o = mk(ent[0], ent[1], ent[2]);
+                d = mk(ent[3], ent[4], ent[5]);
+                w = ent[6];
+                node = (uint32_t)ent[7];
             } else {
                 have = false;
             }

@@ -23,12 +23,11 @@ __device__ __forceinline__ void flush_counters(const KArgs& a, const uint32_t (&
 
 // One wave per 8x8 pixel tile of the strip.
 template <int MW, bool COUNT>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void whitted_kernel(KArgs a) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? 4 : 3, 4))) void whitted_kernel(KArgs a) {
     extern __shared__ double lds_stack[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int entries = a.max_depth > 3 ? a.max_depth - 2 : 1;
-    double* stk = lds_stack + (size_t)wave * entries * kStackFields * 64 + lane;
+    double* stk = lds_stack + (size_t)wave * stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
     const int tx = blockIdx.x * kWavesPerBlock + wave;  // a block = 4 tiles side by side
     const int ty = blockIdx.y;
     const int x = tx * kTile + (lane & 7);
