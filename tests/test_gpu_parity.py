@@ -106,6 +106,40 @@ def test_glass_depth8(tracer):
     assert int(np.bitwise_count(ora["spawn_mask"]).sum(axis=-1).max()) > 64
 
 
+@pytest.mark.parametrize("n_spheres", [0, 1, 3, 4, 6, 7, 8, 11])
+def test_object_counts(tracer, n_spheres):
+    """Scenes of 1..12 objects: the kernel reads the scene in groups of four records plus a
+    guarded remainder, so every count modulo 4 (with and without whole groups) is rendered."""
+    prims, lights = scenes.glass_scene(n_spheres=n_spheres, n_lights=3, seed=0xC0FFEE + n_spheres)
+    assert len(prims) == n_spheres + 1
+    p = abi.make_params(96, 64, 6)
+    dev, ora = _both(tracer, prims, lights, p)
+    assert_parity(dev, ora, f"{n_spheres} spheres + plane")
+
+
+def test_plane_box(tracer):
+    """A room of six planes (floor, ceiling, four walls, two of them tilted) with spheres
+    inside: every ray and every shadow feeler ends on a plane, grazing hits included."""
+    k = (0.6, 0.6, 0.6)
+    prims = [
+        scenes.plane((0, -3, 0), (0, 1, 0), k, reflectivity=0.3),
+        scenes.plane((0, 9, 0), (0, -1, 0), k, reflectivity=0.0),
+        scenes.plane((-8, 0, 0), (1, 0.05, 0.1), (0.8, 0.3, 0.3), reflectivity=0.5),
+        scenes.plane((8, 0, 0), (-1, 0, 0), (0.3, 0.8, 0.3), reflectivity=0.5),
+        scenes.plane((0, 0, 30), (0.02, 0, -1), (0.3, 0.3, 0.8), reflectivity=0.9),
+        scenes.plane((0, 0, -1), (0, 0, 1), k, reflectivity=0.0),
+        scenes.sphere((-2, -1, 12), 2.0, (1, 1, 1), reflectivity=0.9, transparency=0.9, refraction_index=1.5),
+        scenes.sphere((3, 0, 16), 3.0, (0.9, 0.8, 0.2), reflectivity=1.0),
+    ]
+    lights = [scenes.point_light((1, 1, 1), 0.6, (0, 8, 10)), scenes.point_light((1, 0.9, 0.8), 0.3, (-6, 2, 2))]
+    prims = scenes._stack(prims, abi.PRIM_DTYPE)
+    lights = scenes._stack(lights, abi.LIGHT_DTYPE)
+    p = abi.make_params(160, 120, 7)
+    dev, ora = _both(tracer, prims, lights, p)
+    assert_parity(dev, ora, "plane box")
+    assert int(ora["counters"]["feelers_occluded"]) > 0
+
+
 @pytest.mark.parametrize("band_rows,step", [(1, 2), (8, 2), (8, 8), (16, 3), (5, 4)])
 def test_strips_reassemble(tracer, band_rows, step):
     """Rendering the frame as `step` interleaved strips gives the same bytes as the
