@@ -6,13 +6,20 @@
 A step is one frame.  The default workload is the configuration the headline metric is
 quoted on: the reference's default scene at 3840x2160, recursion depth 5.
 
-  N = 1       the whole frame on one GPU.
+  N = 1       a step is one frame, the whole frame on one GPU.
   N > 1       launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py
-              --gpus N ...`, one rank per GPU.  mode strips (default): every frame is cut
-              into interleaved 8-row bands, each rank renders its strip and one RCCL gather
-              brings the 8-bit strips to rank 0 (total work fixed: strong scaling).
-              mode batch: frame f of a camera orbit goes to rank f mod N, no collective
-              (work per GPU fixed: weak scaling).
+              --gpus N ...`, one rank per GPU.
+              mode strips (default): a step is a batch of N frames, frame j owned by rank
+              j.  Every frame is cut into interleaved 8-row bands, every rank renders its
+              strip of each of the N frames (N launches, one frame's worth of pixels) and
+              ONE RCCL all-to-all moves strip (rank r, frame j) to rank j: the strip gather
+              for N frames at once with a different root per frame, so that all xGMI links
+              carry the same share.  The exchange of batch b overlaps the render of batch
+              b+1.  Work per GPU and step is fixed: weak scaling.
+              mode gather: a step is ONE frame, strips gathered to rank 0 (the latency
+              path; total work fixed: strong scaling).
+              mode batch: a step is one whole frame of a camera orbit per rank, no
+              collective (weak scaling).
 
 Rank 0 prints ONE JSON line.  value = rays of all frames of all ranks / wall time of the
 timed steps (max over ranks), with scene and buffers resident in HBM before the clock
@@ -147,7 +154,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--mode", choices=("strips", "batch"), default="strips")
+    ap.add_argument("--mode", choices=("strips", "gather", "batch"), default="strips")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="default_4k_d5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default=None, help="rank 0: write the last frame as BMP to this path")
@@ -165,11 +172,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and not os.environ.get("RT_BENCH_SHARE_GPU"):
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible")
+    local_rank %= n_dev  # RT_BENCH_SHARE_GPU=1: rehearsal of the N>1 code on fewer GPUs
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("RT_BENCH_BACKEND", "nccl")  # "gloo": rehearsal only (host-staged exchange)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     builder, width, height, depth = WORKLOADS[args.workload]
     prims, lights = builder()
@@ -179,14 +194,18 @@ def main():
     stream = torch.cuda.current_stream()
 
     # ---- what this rank renders per step ------------------------------------------------
-    if args.mode == "strips" or world == 1:
-        mode = "strips"
-        my = strips.rank_params(base, rank, world)
-        scaling = "strong" if world > 1 else "weak"
-    else:
-        mode = "batch"
+    if world == 1:
+        mode, scaling, frames_per_step = "single", "weak", 1
         my = base.copy()
-        scaling = "weak"
+    elif args.mode == "strips":
+        mode, scaling, frames_per_step = "strips", "weak", world
+        my = strips.rank_params(base, rank, world)
+    elif args.mode == "gather":
+        mode, scaling, frames_per_step = "gather", "strong", 1
+        my = strips.rank_params(base, rank, world)
+    else:
+        mode, scaling, frames_per_step = "batch", "weak", world
+        my = base.copy()
     my_rows = abi.strip_rows(my)
 
     # untimed counter launch: rays and event counts of this rank's share of one frame
@@ -198,47 +217,87 @@ def main():
     torch.cuda.synchronize()
     cnt_host = d_cnt.cpu().numpy().astype(np.uint64)
     counters = {f: int(cnt_host[i]) for i, f in enumerate(abi.COUNTER_FIELDS)}
-    my_flops = algorithmic_flops(counters, my_rows * width)
+    my_flops = algorithmic_flops(counters, my_rows * width)  # of ONE launch of this rank
     my_rays = counters["rays"]
 
+    # HIP events around the launches of every timed step, on the streams they run on
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     step_no = [0]
+    rays_done = [0]  # rays this rank traced in the timed steps
+    launches_per_step = world if mode == "strips" else 1
 
-    def render_strip(params, out):
-        i = step_no[0] - args.warmup
-        if 0 <= i < args.steps:
-            ev[i][0].record(stream)
-        tracer.render_device(params, stream.cuda_stream, out.data_ptr())
-        if 0 <= i < args.steps:
-            ev[i][1].record(stream)
+    def timed(i):
+        return 0 <= i < args.steps
 
-    if mode == "strips":
+    if mode in ("single", "gather"):
+
+        def render_strip(params, out):
+            i = step_no[0] - args.warmup
+            if timed(i):
+                ev[i][0].record(stream)
+            tracer.render_device(params, stream.cuda_stream, out.data_ptr())
+            if timed(i):
+                ev[i][1].record(stream)
+
         gatherer = strips.StripGatherer(base, render_strip, device)
 
         def step():
             slot = gatherer.submit()
+            if timed(step_no[0] - args.warmup):
+                rays_done[0] += my_rays
             step_no[0] += 1
             return slot
+
+    elif mode == "strips":
+        # the N launches of a batch go round-robin over side streams so that the tail of
+        # one overlaps the head of the next; the exchange on `stream` waits for all of them
+        fan = strips.StreamFan(torch, device, stream, min(4, world))
+
+        def render_strip(j, params, out):
+            i = step_no[0] - args.warmup
+            st = fan.stream_for(j)
+            if j == 0 and timed(i):
+                ev[i][0].record(st)
+            tracer.render_device(params, st.cuda_stream, out.data_ptr())
+            if j == world - 1:
+                fan.join()
+                if timed(i):
+                    ev[i][1].record(stream)
+
+        gatherer = strips.StripExchange(base, render_strip, device)
+
+        def step():
+            slot = gatherer.submit()
+            if timed(step_no[0] - args.warmup):
+                rays_done[0] += my_rays * world  # this rank's strip of each of the N frames
+            step_no[0] += 1
+            return slot
+
     else:
         # orbit batch: this rank's frames are different views of the scene; the scene of
-        # every view is uploaded before the clock starts, one context per view in flight
-        # is not needed because uploads are tiny and synchronous, so views are pre-built.
+        # every view is uploaded before the clock starts.
+        gatherer = None
         n_views = 8
-        views = []
+        views, view_rays = [], []
         for v in range(n_views):
             t = DeviceTracer(local_rank)
             pr, lt = scenes.orbit_scene(prims, lights, 2 * math.pi * (rank * n_views + v) / (world * n_views))
             t.upload_scene(pr, lt)
+            d_cnt.zero_()
+            t.render_device(pc, stream.cuda_stream, scratch.data_ptr(), d_counters=d_cnt.data_ptr())
+            torch.cuda.synchronize()
+            view_rays.append(int(d_cnt[0].item()))
             views.append(t)
         out = [torch.zeros((height, width, 3), dtype=torch.uint8, device=device) for _ in range(2)]
 
         def step():
             i = step_no[0] - args.warmup
-            if 0 <= i < args.steps:
+            if timed(i):
                 ev[i][0].record(stream)
             views[step_no[0] % n_views].render_device(base, stream.cuda_stream, out[step_no[0] & 1].data_ptr())
-            if 0 <= i < args.steps:
+            if timed(i):
                 ev[i][1].record(stream)
+                rays_done[0] += view_rays[step_no[0] % n_views]
             step_no[0] += 1
             return 0
 
@@ -250,38 +309,39 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if mode == "strips":
+    if gatherer is not None:
         gatherer.drain()
     fence()
     t0 = time.perf_counter()
     last = 0
     for _ in range(args.steps):
         last = step()
-    if mode == "strips":
+    if gatherer is not None:
         gatherer.drain()
     fence()
     elapsed = time.perf_counter() - t0
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    # mean duration of one launch (in strips mode: span of a batch's launches / their number)
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / launches_per_step if args.steps else float("nan")
 
     # max over ranks of the wall time, sum over ranks of the rays
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([my_rays], dtype=torch.int64, device=device)
+        r = torch.tensor([rays_done[0]], dtype=torch.int64, device=device)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays_per_step = int(r.item())
+        rays_total = int(r.item())
     else:
-        rays_per_step = my_rays
+        rays_total = rays_done[0]
 
     if rank == 0:
-        if args.dump and mode == "strips":
+        if args.dump and gatherer is not None:
             from raytracer_amd.frame import write_bmp
 
             write_bmp(args.dump, gatherer.frame(last).cpu().numpy())
         ms_per_step = elapsed / args.steps * 1e3
-        value = rays_per_step * args.steps / elapsed / 1e6
+        value = rays_total / elapsed / 1e6
         achieved = my_flops / (kernel_ms * 1e-3) / 1e12
         fb_bytes = my_rows * width * 3
         line = {
@@ -300,8 +360,10 @@ def main():
             "config": {
                 "workload": f"{args.workload}: {width}x{height}, max_depth {depth}, {len(prims)} objects, "
                             f"{len(lights)} lights",
-                "mode": mode if world > 1 else "single",
-                "rays_per_frame": rays_per_step,
+                "mode": mode,
+                "backend": (dist.get_backend() if world > 1 else None),
+                "frames_per_step": frames_per_step,
+                "rays_per_step": rays_total / max(args.steps, 1),
                 "band_rows": strips.DEFAULT_BAND_ROWS,
             },
             "roofline": {

@@ -114,6 +114,8 @@ class StripGatherer:
             self.src = torch.from_numpy(frame_gather_map(self.base, self.world, band_rows)).to(device)
         self.pending = [None, None]
         self.turn = 0
+        # see StripExchange.staged
+        self.staged = self.world > 1 and dist.get_backend(group) == "gloo" and torch.device(device).type != "cpu"
 
     def submit(self):
         """Render this rank's strip of the next frame and start its gather.  Returns the
@@ -125,6 +127,13 @@ class StripGatherer:
             self.pending[s] = None
         self.render_strip(self.params, self.send[s][: self.rows])
         if self.world == 1:
+            return s
+        if self.staged:
+            host = [self.torch.empty(self.send[s].shape, dtype=self.torch.uint8) for _ in range(self.world)]
+            self.dist.gather(self.send[s].cpu(), host if self.rank == 0 else None, dst=0, group=self.group)
+            if self.rank == 0:
+                for dst, src in zip(self.recv[s], host):
+                    dst.copy_(src)
             return s
         self.pending[s] = self.dist.gather(
             self.send[s], self.recv[s] if self.rank == 0 else None, dst=0, group=self.group, async_op=True
@@ -148,3 +157,109 @@ class StripGatherer:
     def drain(self):
         for s in (0, 1):
             self.wait(s)
+
+
+class StripExchange:
+    """A batch of `world` frames per call: frame slot j is owned by rank j, every rank
+    renders its strip of every frame of the batch, and ONE all-to-all (RCCL over xGMI on
+    the GPUs, gloo on CPU ranks) moves strip (rank r, frame j) to rank j.  This is the
+    gather above run for `world` frames at once with a different root per frame, so every
+    xGMI link and every GPU's HBM carries the same share and no rank is the bottleneck.
+    Work per GPU and per call is one frame's worth of pixels whatever the world size.
+
+    render_strip(j, params, out) must fill `out` ([rows, width, 3] uint8 torch tensor on
+    `device`) with this rank's strip (described by `params`) of frame slot j of the
+    current batch, enqueued so that the current stream sees it complete.  Two buffer sets
+    alternate: the exchange of batch b overlaps the render of batch b+1.
+    """
+
+    def __init__(self, base, render_strip, device, group=None, band_rows: int = DEFAULT_BAND_ROWS):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.group = group
+        if dist.is_available() and dist.is_initialized():
+            self.rank = dist.get_rank(group)
+            self.world = dist.get_world_size(group)
+        else:
+            self.rank, self.world = 0, 1
+        self.base = np.array(base, dtype=abi.PARAMS_DTYPE)
+        self.params = rank_params(self.base, self.rank, self.world, band_rows)
+        self.rows = abi.strip_rows(self.params)
+        self.max_rows = max_strip_rows(self.base, self.world, band_rows)
+        self.width = int(self.base["width"])
+        self.render_strip = render_strip
+        shape = (self.world, self.max_rows, self.width, 3)
+        self.send = [torch.zeros(shape, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = [torch.zeros(shape, dtype=torch.uint8, device=device) for _ in range(2)] if self.world > 1 else None
+        self.src = torch.from_numpy(frame_gather_map(self.base, self.world, band_rows)).to(device)
+        self.pending = [None, None]
+        self.turn = 0
+        # gloo cannot exchange device tensors: stage through the host (rehearsals of the
+        # multi-rank code on a box without one GPU per rank; never the measured path)
+        self.staged = self.world > 1 and dist.get_backend(group) == "gloo" and torch.device(device).type != "cpu"
+
+    def _exchange_staged(self, s):
+        host_send = self.send[s].cpu()
+        host_recv = self.torch.empty_like(host_send)
+        self.dist.all_to_all_single(host_recv, host_send, group=self.group)
+        self.recv[s].copy_(host_recv)
+
+    def submit(self):
+        """Render this rank's strips of the next batch and start the exchange.  Returns
+        the buffer slot; this rank's frame of the batch is complete after wait(slot)."""
+        s = self.turn
+        self.turn ^= 1
+        self.wait(s)
+        for j in range(self.world):
+            self.render_strip(j, self.params, self.send[s][j, : self.rows])
+        if self.staged:
+            self._exchange_staged(s)
+        elif self.world > 1:
+            self.pending[s] = self.dist.all_to_all_single(self.recv[s], self.send[s], group=self.group, async_op=True)
+        return s
+
+    def wait(self, slot: int):
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+
+    def frame(self, slot: int):
+        """The assembled [height, width, 3] frame this rank owns in the batch of `slot`."""
+        self.wait(slot)
+        buf = self.send[slot] if self.world == 1 else self.recv[slot]
+        return buf.reshape(-1, self.width, 3).index_select(0, self.src)
+
+    def drain(self):
+        for s in (0, 1):
+            self.wait(s)
+
+
+class StreamFan:
+    """Spreads the kernel launches of one batch over a few side streams, so that the tail
+    of one launch overlaps the head of the next, and joins them back into `main`.
+
+    Per batch: first(j == 0) records on `main` the point after which the output buffers are
+    free; every launch waits for that point only (not for the other launches); after the
+    last launch `main` waits for every side stream, so work enqueued on `main` afterwards
+    (a collective, a copy) sees the whole batch complete.
+    """
+
+    def __init__(self, torch, device, main, n_side: int):
+        self.main = main
+        self.side = [torch.cuda.Stream(device=device) for _ in range(max(1, n_side))]
+        self.free = torch.cuda.Event()
+
+    def stream_for(self, j: int):
+        """Call once per launch, in order j = 0, 1, ...: the stream to launch on."""
+        if j == 0:
+            self.free.record(self.main)
+        st = self.side[j % len(self.side)]
+        st.wait_event(self.free)
+        return st
+
+    def join(self):
+        """Call after the last launch of the batch."""
+        for q in self.side:
+            self.main.wait_stream(q)

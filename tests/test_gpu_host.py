@@ -79,3 +79,42 @@ def test_strip_gatherer_on_gpu_single_rank(tracer):
     got = g.frame(slots[-1]).cpu().numpy()
     want = tracer.render(base, want_ids=False, want_masks=False)["bgr"]
     assert np.array_equal(got, want)
+
+
+def test_strip_exchange_and_stream_fan_on_gpu(tracer):
+    """The launch pattern of the multi-GPU bench on one GPU: the strips of a frame, cut for
+    a world of 4, are rendered as the 4 launches of a batch over side streams, joined into
+    the main stream and re-assembled there; three batches reuse both buffer sets."""
+    import torch
+
+    prims, lights = scenes.default_scene()
+    tracer.upload_scene(prims, lights)
+    world = 4
+    base = abi.make_params(640, 203, 5)
+    dev = torch.device("cuda", 0)
+    main = torch.cuda.current_stream()
+    fan = strips.StreamFan(torch, dev, main, 3)
+    mr = strips.max_strip_rows(base, world)
+    src = torch.from_numpy(strips.frame_gather_map(base, world)).to(dev)
+    bufs = [torch.zeros((world, mr, 640, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    want = tracer.render(base, want_ids=False, want_masks=False)["bgr"]
+    for batch in range(3):
+        buf = bufs[batch & 1]
+        buf.fill_(7)  # on `main`: the launches must not start before this
+        for j in range(world):
+            p = strips.rank_params(base, j, world)
+            st = fan.stream_for(j)
+            tracer.render_device(p, st.cuda_stream, buf[j, : abi.strip_rows(p)].data_ptr())
+        fan.join()
+        frame = buf.reshape(-1, 640, 3).index_select(0, src)  # on `main`, after the join
+        assert np.array_equal(frame.cpu().numpy(), want), batch
+
+    # the same through StripExchange with a single rank (no collective)
+    def render_strip(j, params, out):
+        st = fan.stream_for(j)
+        tracer.render_device(params, st.cuda_stream, out.data_ptr())
+        fan.join()
+
+    x = strips.StripExchange(base, render_strip, dev)
+    slots = [x.submit() for _ in range(3)]
+    assert np.array_equal(x.frame(slots[-1]).cpu().numpy(), want)

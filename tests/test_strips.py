@@ -111,3 +111,68 @@ def test_strip_gatherer_single_process():
     s = g.submit()
     want = oracle_lib.render(prims, lights, base, want_ids=False, want_masks=False)["bgr"]
     assert np.array_equal(g.frame(s).numpy(), want)
+
+
+def _exchange_worker(rank, world, port, width, height, depth, batches, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from tests import oracle_lib
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        prims, lights = scenes.default_scene()
+        base = abi.make_params(width, height, depth)
+        batch_no = [-1]
+
+        def view(batch, slot):  # a different scene per frame of every batch
+            return scenes.orbit_scene(prims, lights, 0.15 * (batch * world + slot))
+
+        def render_strip(j, params, out):
+            if j == 0:
+                batch_no[0] += 1
+            pr, lt = view(batch_no[0], j)
+            out.copy_(torch.from_numpy(oracle_lib.render(pr, lt, params, want_ids=False, want_masks=False)["bgr"]))
+
+        x = strips.StripExchange(base, render_strip, torch.device("cpu"), band_rows=8)
+        assert x.world == world and x.rank == rank
+        slots = [x.submit() for _ in range(batches)]
+        got = x.frame(slots[-1]).numpy().copy()
+        x.drain()
+        pr, lt = view(batches - 1, rank)  # this rank owns frame slot `rank` of the batch
+        want = oracle_lib.render(pr, lt, base, want_ids=False, want_masks=False)["bgr"]
+        np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([int(np.array_equal(got, want)), got.shape[0]]))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("height", [50, 64])
+def test_strip_exchange_two_ranks_gloo(tmp_path, height):
+    """Batch of `world` frames, strips exchanged with one all-to-all: every rank ends up
+    with the whole frame it owns, three batches deep so that both buffer sets are reused."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_exchange_worker, args=(2, _free_port(), 72, height, 4, 3, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        ok, rows = np.load(tmp_path / f"r{r}.npy")
+        assert rows == height and ok == 1
+
+
+def test_strip_exchange_single_process():
+    import torch
+
+    from tests import oracle_lib
+
+    prims, lights = scenes.default_scene()
+    base = abi.make_params(40, 30, 4)
+
+    def render_strip(j, params, out):
+        out.copy_(torch.from_numpy(oracle_lib.render(prims, lights, params, want_ids=False, want_masks=False)["bgr"]))
+
+    x = strips.StripExchange(base, render_strip, torch.device("cpu"))
+    s = x.submit()
+    want = oracle_lib.render(prims, lights, base, want_ids=False, want_masks=False)["bgr"]
+    assert np.array_equal(x.frame(s).numpy(), want)
