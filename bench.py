@@ -11,7 +11,7 @@ quoted on: the reference's default scene at 3840x2160, recursion depth 5.
               --gpus N ...`, one rank per GPU.
               mode strips (default): a step is a batch of N frames, frame j owned by rank
               j.  Every frame is cut into interleaved 8-row bands, every rank renders its
-              strip of each of the N frames (N launches, one frame's worth of pixels) and
+              strip of each of the N frames (one batched launch, a frame's worth of pixels) and
               ONE RCCL all-to-all moves strip (rank r, frame j) to rank j: the strip gather
               for N frames at once with a different root per frame, so that all xGMI links
               carry the same share.  The exchange of batch b overlaps the render of batch
@@ -224,7 +224,7 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     step_no = [0]
     rays_done = [0]  # rays this rank traced in the timed steps
-    launches_per_step = world if mode == "strips" else 1
+    renders_per_launch = world if mode == "strips" else 1  # strips: one batched launch of N strips
 
     def timed(i):
         return 0 <= i < args.steps
@@ -249,22 +249,22 @@ def main():
             return slot
 
     elif mode == "strips":
-        # the N launches of a batch go round-robin over side streams so that the tail of
-        # one overlaps the head of the next; the exchange on `stream` waits for all of them
-        fan = strips.StreamFan(torch, device, stream, min(4, world))
+        # one batched launch per step: this rank's strip of each of the N frames
+        from raytracer_amd.device import BatchPlan
 
-        def render_strip(j, params, out):
+        plans = {}
+
+        def render_strips(slot, params, outs):
             i = step_no[0] - args.warmup
-            st = fan.stream_for(j)
-            if j == 0 and timed(i):
-                ev[i][0].record(st)
-            tracer.render_device(params, st.cuda_stream, out.data_ptr())
-            if j == world - 1:
-                fan.join()
-                if timed(i):
-                    ev[i][1].record(stream)
+            if slot not in plans:
+                plans[slot] = BatchPlan([tracer] * world, [params] * world, [o.data_ptr() for o in outs])
+            if timed(i):
+                ev[i][0].record(stream)
+            plans[slot].launch(stream.cuda_stream)
+            if timed(i):
+                ev[i][1].record(stream)
 
-        gatherer = strips.StripExchange(base, render_strip, device)
+        gatherer = strips.StripExchange(base, render_strips, device)
 
         def step():
             slot = gatherer.submit()
@@ -321,8 +321,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    # mean duration of one launch (in strips mode: span of a batch's launches / their number)
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / launches_per_step if args.steps else float("nan")
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    my_flops *= renders_per_launch
+    my_rows *= renders_per_launch
 
     # max over ranks of the wall time, sum over ranks of the rays
     if world > 1:
@@ -373,7 +374,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                 "traffic": _traffic_bytes(args.workload) if world == 1 else None,
-                "kernel": "whitted_kernel<0,false>",
+                "kernel": "whitted_batch_kernel" if mode == "strips" else "whitted_kernel<0,false>",
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": my_flops,
                 "framebuffer_write_GBps": fb_bytes / (kernel_ms * 1e-3) / 1e9,

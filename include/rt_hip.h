@@ -171,6 +171,17 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
                      rt_counters* d_counters);
 
 /*
+ * n image-only renders on one device with ONE kernel launch, enqueued on `stream`: render i
+ * uses the scene of ctxs[i] (contexts may repeat), params[i] (flags must be 0) and writes
+ * rows*width*3 bytes to the device buffer d_bgr[i].  It is what one rank of the multi-GPU
+ * path does per step: its strip of each frame of a batch of frames, every frame with its
+ * own camera/scene.  In the reference this is n calls of Tracer() (src/main.cc:115-141) on
+ * n scenes, restricted to the rows of each partition.  Errors are reported on ctxs[0].
+ */
+int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t n,
+                           void* stream, uint8_t* const* d_bgr);
+
+/*
  * Test hooks: run the device versions of the reference's collision tests and of the
  * vector normalisation on caller-supplied rays, so that their double results can be
  * compared bit for bit with a CPU evaluation.

@@ -293,6 +293,35 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
     return RT_OK;
 }
 
+int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t n, void* stream,
+                           uint8_t* const* d_bgr) {
+    if (!ctxs || n < 1 || !ctxs[0]) return RT_ERR_ARG;
+    rt_ctx* first = ctxs[0];
+    if (!params || !d_bgr) return fail(first, RT_ERR_ARG, "rt_render_device_batch: null argument");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || !d_bgr[i]) return fail(first, RT_ERR_ARG, "rt_render_device_batch: null context or output");
+        if (ctxs[i]->device != first->device)
+            return fail(first, RT_ERR_ARG, "rt_render_device_batch: contexts on different devices");
+        if (params[i].flags != 0) return fail(first, RT_ERR_ARG, "rt_render_device_batch: flags must be 0");
+    }
+    RT_HIP_TRY(first, hipSetDevice(first->device));
+    for (int base = 0; base < n; base += rt::kMaxBatch) {
+        const int m = (n - base < rt::kMaxBatch) ? n - base : rt::kMaxBatch;
+        rt::KBatch b;
+        std::memset(&b, 0, sizeof b);
+        for (int i = 0; i < m; ++i) {
+            int rc = make_args(ctxs[base + i], &params[base + i], b.a[i]);
+            if (rc != RT_OK) {
+                if (ctxs[base + i] != first) first->err = ctxs[base + i]->err;
+                return rc;
+            }
+            b.a[i].bgr = d_bgr[base + i];
+        }
+        RT_HIP_TRY(first, rt::launch_whitted_batch(b, m, static_cast<hipStream_t>(stream)));
+    }
+    return RT_OK;
+}
+
 int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id, uint32_t* hit_mask,
               uint32_t* spawn_mask, rt_counters* counters) {
     if (!ctx) return RT_ERR_ARG;

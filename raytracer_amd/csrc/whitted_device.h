@@ -90,6 +90,14 @@ inline size_t stack_lds_bytes(int max_depth) {
     return (size_t)kWavesPerBlock * stack_lds_entries(max_depth) * kStackFields * 64 * sizeof(double);
 }
 
+// Arguments of up to kMaxBatch renders done by one launch (kernel argument segment: 4 KB).
+constexpr int kMaxBatch = 8;
+struct KBatch {
+    KArgs a[kMaxBatch];
+};
+static_assert(sizeof(KBatch) <= 3072, "kernel argument segment");
+hipError_t launch_whitted_batch(const KBatch& b, int n, hipStream_t stream);
+
 // Enqueue the render of one strip on `stream`.  emit = write hit_id/masks (pointers in
 // `a` that are null are skipped), count = add event counts to a.counters.
 hipError_t launch_whitted(const KArgs& a, bool emit, bool count, hipStream_t stream);

@@ -47,6 +47,41 @@ static hipError_t launch_t(const KArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// Several renders in one launch: blockIdx.z selects the render (its scene tables, camera,
+// partition and output), the arguments of all of them travel by value in the kernel
+// argument segment.  Image-only variant; the grid is sized for the largest render, blocks
+// outside a smaller one return at once.
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void whitted_batch_kernel(KBatch b) {
+    extern __shared__ double lds_stack[];
+    const KArgs& a = b.a[blockIdx.z];
+    if ((int)blockIdx.y >= a.tiles_y || (int)(blockIdx.x * kWavesPerBlock) >= a.tiles_x) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double* stk = lds_stack + (size_t)wave * stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
+    const int tx = blockIdx.x * kWavesPerBlock + wave;
+    const int ty = blockIdx.y;
+    const int x = tx * kTile + (lane & 7);
+    const int k = ty * kTile + (lane >> 3);
+    const bool have = (x < a.width) && (k < a.rows);
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    trace_pixel<0, false>(a, x, k, have, stk, cnt);
+}
+
+hipError_t launch_whitted_batch(const KBatch& b, int n, hipStream_t stream) {
+    int bx = 0, by = 0, depth = 0;
+    for (int i = 0; i < n; ++i) {
+        const KArgs& a = b.a[i];
+        bx = max(bx, (a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock);
+        by = max(by, a.tiles_y);
+        depth = max(depth, a.max_depth);
+    }
+    if (n <= 0 || bx <= 0 || by <= 0) return hipSuccess;
+    hipLaunchKernelGGL(whitted_batch_kernel, dim3(bx, by, n), dim3(64 * kWavesPerBlock), stack_lds_bytes(depth), stream,
+                       b);
+    return hipGetLastError();
+}
+
 hipError_t launch_whitted(const KArgs& a, bool emit, bool count, hipStream_t stream) {
     const int mw = emit ? a.mask_words : 0;
     if (count) {

@@ -27,6 +27,7 @@ EXPORTS = (
     "rt_upload_scene",
     "rt_render",
     "rt_render_device",
+    "rt_render_device_batch",
     "rt_debug_intersect",
 )
 
@@ -60,6 +61,7 @@ def load_library():
     L.rt_upload_scene.restype, L.rt_upload_scene.argtypes = ctypes.c_int, [vp, vp, i32, vp, i32]
     L.rt_render.restype, L.rt_render.argtypes = ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp]
     L.rt_render_device.restype, L.rt_render_device.argtypes = ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rt_render_device_batch.restype, L.rt_render_device_batch.argtypes = ctypes.c_int, [vp, vp, i32, vp, vp]
     L.rt_debug_intersect.restype, L.rt_debug_intersect.argtypes = ctypes.c_int, [vp, vp, i32, i32, vp, vp, vp]
     _lib = L
     return L
@@ -146,3 +148,27 @@ class DeviceTracer:
         unit = np.zeros((n, 3), dtype=np.float64)
         self._check(self._L.rt_debug_intersect(self._h, _ptr(rays), n, prim, _ptr(t), _ptr(hit), _ptr(unit)))
         return t, hit, unit
+
+
+class BatchPlan:
+    """Prebuilt arguments of rt_render_device_batch: n renders in one launch, render i with
+    tracers[i]'s scene, params[i], output device address d_bgr[i].  Building the plan once
+    and calling launch(stream) per step keeps the per-step host cost to one foreign call."""
+
+    def __init__(self, tracers, params, d_bgr):
+        n = len(tracers)
+        if not (n == len(params) == len(d_bgr)) or n == 0:
+            raise ValueError("BatchPlan: tracers, params and d_bgr must have the same non-zero length")
+        self._tracers = list(tracers)  # keep the contexts alive
+        self._L = tracers[0]._L
+        self._n = n
+        self._ctxs = (ctypes.c_void_p * n)(*[t._h for t in tracers])
+        self._params = np.ascontiguousarray(np.stack([np.array(p, dtype=abi.PARAMS_DTYPE) for p in params]))
+        self._out = (ctypes.c_void_p * n)(*[ctypes.c_void_p(int(a)) for a in d_bgr])
+
+    def launch(self, stream: int):
+        rc = self._L.rt_render_device_batch(
+            self._ctxs, _ptr(self._params), self._n, ctypes.c_void_p(stream) if stream else None, self._out
+        )
+        if rc != abi.RT_OK:
+            raise RtError(rc, self._L.rt_last_error(self._tracers[0]._h).decode())

@@ -167,13 +167,15 @@ class StripExchange:
     xGMI link and every GPU's HBM carries the same share and no rank is the bottleneck.
     Work per GPU and per call is one frame's worth of pixels whatever the world size.
 
-    render_strip(j, params, out) must fill `out` ([rows, width, 3] uint8 torch tensor on
-    `device`) with this rank's strip (described by `params`) of frame slot j of the
-    current batch, enqueued so that the current stream sees it complete.  Two buffer sets
-    alternate: the exchange of batch b overlaps the render of batch b+1.
+    render_strips(slot, params, outs) must fill outs[j] ([rows, width, 3] uint8 torch tensor
+    on `device`) with this rank's strip (described by `params`) of frame j of the current
+    batch, for every j, enqueued on the current stream (on the GPUs: one batched launch,
+    rt_render_device_batch).  `slot` (0 or 1) tells which of the two alternating buffer
+    sets `outs` belongs to, so that a caller can prebuild its launch arguments per set:
+    the exchange of batch b overlaps the render of batch b+1.
     """
 
-    def __init__(self, base, render_strip, device, group=None, band_rows: int = DEFAULT_BAND_ROWS):
+    def __init__(self, base, render_strips, device, group=None, band_rows: int = DEFAULT_BAND_ROWS):
         import torch
         import torch.distributed as dist
 
@@ -189,10 +191,11 @@ class StripExchange:
         self.rows = abi.strip_rows(self.params)
         self.max_rows = max_strip_rows(self.base, self.world, band_rows)
         self.width = int(self.base["width"])
-        self.render_strip = render_strip
+        self.render_strips = render_strips
         shape = (self.world, self.max_rows, self.width, 3)
         self.send = [torch.zeros(shape, dtype=torch.uint8, device=device) for _ in range(2)]
         self.recv = [torch.zeros(shape, dtype=torch.uint8, device=device) for _ in range(2)] if self.world > 1 else None
+        self.outs = [[self.send[s][j, : self.rows] for j in range(self.world)] for s in range(2)]
         self.src = torch.from_numpy(frame_gather_map(self.base, self.world, band_rows)).to(device)
         self.pending = [None, None]
         self.turn = 0
@@ -212,8 +215,7 @@ class StripExchange:
         s = self.turn
         self.turn ^= 1
         self.wait(s)
-        for j in range(self.world):
-            self.render_strip(j, self.params, self.send[s][j, : self.rows])
+        self.render_strips(s, self.params, self.outs[s])
         if self.staged:
             self._exchange_staged(s)
         elif self.world > 1:
@@ -235,31 +237,3 @@ class StripExchange:
         for s in (0, 1):
             self.wait(s)
 
-
-class StreamFan:
-    """Spreads the kernel launches of one batch over a few side streams, so that the tail
-    of one launch overlaps the head of the next, and joins them back into `main`.
-
-    Per batch: first(j == 0) records on `main` the point after which the output buffers are
-    free; every launch waits for that point only (not for the other launches); after the
-    last launch `main` waits for every side stream, so work enqueued on `main` afterwards
-    (a collective, a copy) sees the whole batch complete.
-    """
-
-    def __init__(self, torch, device, main, n_side: int):
-        self.main = main
-        self.side = [torch.cuda.Stream(device=device) for _ in range(max(1, n_side))]
-        self.free = torch.cuda.Event()
-
-    def stream_for(self, j: int):
-        """Call once per launch, in order j = 0, 1, ...: the stream to launch on."""
-        if j == 0:
-            self.free.record(self.main)
-        st = self.side[j % len(self.side)]
-        st.wait_event(self.free)
-        return st
-
-    def join(self):
-        """Call after the last launch of the batch."""
-        for q in self.side:
-            self.main.wait_stream(q)

@@ -81,40 +81,62 @@ def test_strip_gatherer_on_gpu_single_rank(tracer):
     assert np.array_equal(got, want)
 
 
-def test_strip_exchange_and_stream_fan_on_gpu(tracer):
-    """The launch pattern of the multi-GPU bench on one GPU: the strips of a frame, cut for
-    a world of 4, are rendered as the 4 launches of a batch over side streams, joined into
-    the main stream and re-assembled there; three batches reuse both buffer sets."""
+def test_batched_launch_on_gpu(tracer):
+    """rt_render_device_batch, the per-step launch of the multi-GPU path, on one GPU: the
+    strips of a frame cut for a world of 4 — with a second scene in two of the slots and a
+    smaller frame in one — rendered by ONE launch equal the same strips rendered one by
+    one; then the frame re-assembled from its four strips equals the whole frame, over
+    three rounds that reuse both buffer sets of a StripExchange."""
     import torch
+
+    from raytracer_amd.device import BatchPlan, DeviceTracer
 
     prims, lights = scenes.default_scene()
     tracer.upload_scene(prims, lights)
-    world = 4
-    base = abi.make_params(640, 203, 5)
+    other = DeviceTracer(0)
+    other.upload_scene(*scenes.glass_scene(n_spheres=5, n_lights=2))
     dev = torch.device("cuda", 0)
     main = torch.cuda.current_stream()
-    fan = strips.StreamFan(torch, dev, main, 3)
+    world = 4
+    base = abi.make_params(640, 203, 5)
+    small = abi.make_params(96, 50, 7)
+    tr = [tracer, other, tracer, other]
+    ps = [strips.rank_params(base, 0, world), strips.rank_params(base, 1, world), strips.rank_params(small, 1, 2),
+          strips.rank_params(base, 3, world)]
+    outs = [torch.zeros((abi.strip_rows(p), int(p["width"]), 3), dtype=torch.uint8, device=dev) for p in ps]
+    BatchPlan(tr, ps, [o.data_ptr() for o in outs]).launch(main.cuda_stream)
+    for t, p, o in zip(tr, ps, outs):
+        want = t.render(p, want_ids=False, want_masks=False)["bgr"]
+        assert np.array_equal(o.cpu().numpy(), want)
+    # more renders than one launch holds
+    many = [strips.rank_params(base, j, 11) for j in range(11)]
+    outs = [torch.zeros((abi.strip_rows(p), 640, 3), dtype=torch.uint8, device=dev) for p in many]
+    BatchPlan([tracer] * 11, many, [o.data_ptr() for o in outs]).launch(main.cuda_stream)
+    for p, o in zip(many, outs):
+        assert np.array_equal(o.cpu().numpy(), tracer.render(p, want_ids=False, want_masks=False)["bgr"])
+
+    # a frame as the four strips of one batched launch, through StripExchange's buffers
+    want = tracer.render(base, want_ids=False, want_masks=False)["bgr"]
     mr = strips.max_strip_rows(base, world)
     src = torch.from_numpy(strips.frame_gather_map(base, world)).to(dev)
     bufs = [torch.zeros((world, mr, 640, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-    want = tracer.render(base, want_ids=False, want_masks=False)["bgr"]
+    ps = [strips.rank_params(base, j, world) for j in range(world)]
+    plans = [BatchPlan([tracer] * world, ps, [b[j].data_ptr() for j in range(world)]) for b in bufs]
     for batch in range(3):
-        buf = bufs[batch & 1]
-        buf.fill_(7)  # on `main`: the launches must not start before this
-        for j in range(world):
-            p = strips.rank_params(base, j, world)
-            st = fan.stream_for(j)
-            tracer.render_device(p, st.cuda_stream, buf[j, : abi.strip_rows(p)].data_ptr())
-        fan.join()
-        frame = buf.reshape(-1, 640, 3).index_select(0, src)  # on `main`, after the join
+        bufs[batch & 1].fill_(7)
+        plans[batch & 1].launch(main.cuda_stream)
+        frame = bufs[batch & 1].reshape(-1, 640, 3).index_select(0, src)
         assert np.array_equal(frame.cpu().numpy(), want), batch
 
-    # the same through StripExchange with a single rank (no collective)
-    def render_strip(j, params, out):
-        st = fan.stream_for(j)
-        tracer.render_device(params, st.cuda_stream, out.data_ptr())
-        fan.join()
+    # StripExchange with a single rank (no collective), plan per buffer set
+    x_plans = {}
 
-    x = strips.StripExchange(base, render_strip, dev)
+    def render_strips(slot, params, outs):
+        if slot not in x_plans:
+            x_plans[slot] = BatchPlan([tracer], [params], [outs[0].data_ptr()])
+        x_plans[slot].launch(main.cuda_stream)
+
+    x = strips.StripExchange(base, render_strips, dev)
     slots = [x.submit() for _ in range(3)]
     assert np.array_equal(x.frame(slots[-1]).cpu().numpy(), want)
+    other.close()

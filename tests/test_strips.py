@@ -130,13 +130,14 @@ def _exchange_worker(rank, world, port, width, height, depth, batches, out_dir):
         def view(batch, slot):  # a different scene per frame of every batch
             return scenes.orbit_scene(prims, lights, 0.15 * (batch * world + slot))
 
-        def render_strip(j, params, out):
-            if j == 0:
-                batch_no[0] += 1
-            pr, lt = view(batch_no[0], j)
-            out.copy_(torch.from_numpy(oracle_lib.render(pr, lt, params, want_ids=False, want_masks=False)["bgr"]))
+        def render_strips(slot, params, outs):
+            batch_no[0] += 1
+            assert slot == batch_no[0] % 2 and len(outs) == world
+            for j, out in enumerate(outs):
+                pr, lt = view(batch_no[0], j)
+                out.copy_(torch.from_numpy(oracle_lib.render(pr, lt, params, want_ids=False, want_masks=False)["bgr"]))
 
-        x = strips.StripExchange(base, render_strip, torch.device("cpu"), band_rows=8)
+        x = strips.StripExchange(base, render_strips, torch.device("cpu"), band_rows=8)
         assert x.world == world and x.rank == rank
         slots = [x.submit() for _ in range(batches)]
         got = x.frame(slots[-1]).numpy().copy()
@@ -169,10 +170,10 @@ def test_strip_exchange_single_process():
     prims, lights = scenes.default_scene()
     base = abi.make_params(40, 30, 4)
 
-    def render_strip(j, params, out):
-        out.copy_(torch.from_numpy(oracle_lib.render(prims, lights, params, want_ids=False, want_masks=False)["bgr"]))
+    def render_strips(slot, params, outs):
+        outs[0].copy_(torch.from_numpy(oracle_lib.render(prims, lights, params, want_ids=False, want_masks=False)["bgr"]))
 
-    x = strips.StripExchange(base, render_strip, torch.device("cpu"))
+    x = strips.StripExchange(base, render_strips, torch.device("cpu"))
     s = x.submit()
     want = oracle_lib.render(prims, lights, base, want_ids=False, want_masks=False)["bgr"]
     assert np.array_equal(x.frame(s).numpy(), want)
