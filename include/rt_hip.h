@@ -74,6 +74,11 @@ typedef struct rt_light {
 
 /* rt_params.flags */
 #define RT_FLAG_COUNTERS 1u   /* also count events into rt_counters (slower kernel)      */
+#define RT_FLAG_LINEAR 2u     /* test every object in container order, as the reference
+                                 does (src/main.cc:37-47), whatever the scene size       */
+#define RT_FLAG_TREE 4u       /* walk the sphere tree even for a small scene.  Without
+                                 either flag the tree is used from 32 spheres on.  The
+                                 results are identical bit for bit in both modes.        */
 
 /*
  * Per-render parameters: the values the reference hard-wires in Tracer()/main()
@@ -172,7 +177,8 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
 
 /*
  * n image-only renders on one device with ONE kernel launch, enqueued on `stream`: render i
- * uses the scene of ctxs[i] (contexts may repeat), params[i] (flags must be 0) and writes
+ * uses the scene of ctxs[i] (contexts may repeat), params[i] (no RT_FLAG_COUNTERS; all
+ * renders with or all without the sphere tree) and writes
  * rows*width*3 bytes to the device buffer d_bgr[i].  It is what one rank of the multi-GPU
  * path does per step: its strip of each frame of a batch of frames, every frame with its
  * own camera/scene.  In the reference this is n calls of Tracer() (src/main.cc:115-141) on

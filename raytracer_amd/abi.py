@@ -20,6 +20,8 @@ RT_MAX_LIGHTS = 256
 RT_PRIM_PLANE = 0
 RT_PRIM_SPHERE = 1
 RT_FLAG_COUNTERS = 1
+RT_FLAG_LINEAR = 2
+RT_FLAG_TREE = 4
 
 PRIM_DTYPE = np.dtype(
     [

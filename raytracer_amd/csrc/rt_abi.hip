@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "sphere_tree.h"
 #include "whitted_device.h"
 
 #pragma clang fp contract(off)
@@ -34,6 +35,11 @@ struct rt_ctx {
     // float image of the geometry for the certain-miss filter
     rt::FGeom* f_geom = nullptr;
     float scene_p1max = 0.0f;
+    // sphere tree + the planes' records (used when the scene has many spheres)
+    rt::FGeom* f_tree = nullptr;
+    rt::FGeom* f_planes = nullptr;
+    int32_t* d_planes_before = nullptr;
+    int32_t n_nodes = 0, n_planes = 0;
     // grow-only device staging for rt_render's host outputs
     DevBuf bgr, hit_id, hit_mask, spawn_mask, counters, dbg_in, dbg_t, dbg_hit, dbg_unit;
     hipStream_t stream = nullptr;
@@ -80,6 +86,14 @@ int check_params(const rt_params* p) {
 // Fill the kernel arguments for the partition in p.  The camera arithmetic is the
 // ViewFrustum constructor's (src/view_frustum.h:18,28-34), evaluated on the host in
 // double exactly as written there.
+// The tree pays once a ray has more spheres to test than a walk visits nodes.
+constexpr int kTreeMinSpheres = 32;
+bool use_tree(const rt_ctx* ctx, const rt_params* p) {
+    if (p->flags & RT_FLAG_LINEAR) return false;
+    if (p->flags & RT_FLAG_TREE) return ctx->n_nodes > 0;
+    return ctx->n_prims - ctx->n_planes >= kTreeMinSpheres;
+}
+
 int make_args(rt_ctx* ctx, const rt_params* p, rt::KArgs& a) {
     if (check_params(p) != RT_OK) return fail(ctx, RT_ERR_ARG, "rt_params: value out of range");
     if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
@@ -88,6 +102,11 @@ int make_args(rt_ctx* ctx, const rt_params* p, rt::KArgs& a) {
     a.mat = ctx->d_mat;
     a.lights = ctx->d_lights;
     a.fgeom = ctx->f_geom;
+    a.tree = ctx->f_tree;
+    a.planes = ctx->f_planes;
+    a.planes_before = ctx->d_planes_before;
+    a.n_nodes = ctx->n_nodes;
+    a.n_planes = ctx->n_planes;
     a.scene_p1max = ctx->scene_p1max;
     a.n_prims = ctx->n_prims;
     a.n_lights = ctx->n_lights;
@@ -177,6 +196,9 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->d_mat) (void)hipFree(ctx->d_mat);
     if (ctx->d_lights) (void)hipFree(ctx->d_lights);
     if (ctx->f_geom) (void)hipFree(ctx->f_geom);
+    if (ctx->f_tree) (void)hipFree(ctx->f_tree);
+    if (ctx->f_planes) (void)hipFree(ctx->f_planes);
+    if (ctx->d_planes_before) (void)hipFree(ctx->d_planes_before);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -250,10 +272,48 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         }
     }
     for (size_t i = n_prims; i < fgeom.size(); ++i) fgeom[i] = fgeom[n_prims - 1];  // pad to whole groups of 4
+    // sphere tree, the planes' records with their original index, plane prefix counts
+    std::vector<rt::TreeSphere> tsph;
+    std::vector<rt::FGeom> fplanes;
+    std::vector<int32_t> planes_before(static_cast<size_t>(n_prims) + 1, 0);
+    for (int i = 0; i < n_prims; ++i) {
+        const rt_prim& s = prims[i];
+        planes_before[i + 1] = planes_before[i] + (s.type == RT_PRIM_PLANE ? 1 : 0);
+        if (s.type == RT_PRIM_PLANE) {
+            rt::FGeom g = fgeom[i];
+            std::memcpy(&g.v[6], &i, sizeof(int32_t));
+            fplanes.push_back(g);
+        } else {
+            tsph.push_back(rt::TreeSphere{{s.p[0], s.p[1], s.p[2]}, s.q[0], i});
+        }
+    }
+    std::vector<rt::FGeom> tree = rt::build_sphere_tree(tsph);
+    for (const rt::FGeom& nd : tree) {  // the filter's per-ray bound must cover the node centres too
+        const float c1 = (std::fabs(nd.v[0]) + std::fabs(nd.v[1]) + std::fabs(nd.v[2])) * 1.0001f;
+        if (c1 > p1max) p1max = c1;
+    }
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->have_scene = false;
     if (ctx->f_geom) RT_HIP_TRY(ctx, hipFree(ctx->f_geom));
     ctx->f_geom = nullptr;
+    if (ctx->f_tree) RT_HIP_TRY(ctx, hipFree(ctx->f_tree));
+    if (ctx->f_planes) RT_HIP_TRY(ctx, hipFree(ctx->f_planes));
+    if (ctx->d_planes_before) RT_HIP_TRY(ctx, hipFree(ctx->d_planes_before));
+    ctx->f_tree = nullptr; ctx->f_planes = nullptr; ctx->d_planes_before = nullptr;
+    ctx->n_nodes = 0; ctx->n_planes = 0;
+    if (!tree.empty()) {
+        RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->f_tree), tree.size() * sizeof(rt::FGeom)));
+        RT_HIP_TRY(ctx, hipMemcpy(ctx->f_tree, tree.data(), tree.size() * sizeof(rt::FGeom), hipMemcpyHostToDevice));
+    }
+    if (!fplanes.empty()) {
+        RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->f_planes), fplanes.size() * sizeof(rt::FGeom)));
+        RT_HIP_TRY(ctx, hipMemcpy(ctx->f_planes, fplanes.data(), fplanes.size() * sizeof(rt::FGeom), hipMemcpyHostToDevice));
+    }
+    RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_planes_before), planes_before.size() * sizeof(int32_t)));
+    RT_HIP_TRY(ctx, hipMemcpy(ctx->d_planes_before, planes_before.data(), planes_before.size() * sizeof(int32_t),
+                              hipMemcpyHostToDevice));
+    ctx->n_nodes = static_cast<int32_t>(tree.size());
+    ctx->n_planes = static_cast<int32_t>(fplanes.size());
     RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->f_geom), fgeom.size() * sizeof(rt::FGeom)));
     RT_HIP_TRY(ctx, hipMemcpy(ctx->f_geom, fgeom.data(), fgeom.size() * sizeof(rt::FGeom), hipMemcpyHostToDevice));
     ctx->scene_p1max = p1max;
@@ -289,7 +349,7 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
     a.counters = reinterpret_cast<unsigned long long*>(d_counters);
     const bool emit = d_hit_id || d_hit_mask || d_spawn_mask;
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, static_cast<hipStream_t>(stream)));
+    RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, use_tree(ctx, p), static_cast<hipStream_t>(stream)));
     return RT_OK;
 }
 
@@ -302,8 +362,12 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
         if (!ctxs[i] || !d_bgr[i]) return fail(first, RT_ERR_ARG, "rt_render_device_batch: null context or output");
         if (ctxs[i]->device != first->device)
             return fail(first, RT_ERR_ARG, "rt_render_device_batch: contexts on different devices");
-        if (params[i].flags != 0) return fail(first, RT_ERR_ARG, "rt_render_device_batch: flags must be 0");
+        if (params[i].flags & RT_FLAG_COUNTERS)
+            return fail(first, RT_ERR_ARG, "rt_render_device_batch: RT_FLAG_COUNTERS is not supported");
+        if (use_tree(ctxs[i], &params[i]) != use_tree(first, &params[0]))
+            return fail(first, RT_ERR_ARG, "rt_render_device_batch: scenes with and without a sphere tree in one batch");
     }
+    const bool tree = use_tree(first, &params[0]);
     RT_HIP_TRY(first, hipSetDevice(first->device));
     for (int base = 0; base < n; base += rt::kMaxBatch) {
         const int m = (n - base < rt::kMaxBatch) ? n - base : rt::kMaxBatch;
@@ -317,7 +381,7 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
             }
             b.a[i].bgr = d_bgr[base + i];
         }
-        RT_HIP_TRY(first, rt::launch_whitted_batch(b, m, static_cast<hipStream_t>(stream)));
+        RT_HIP_TRY(first, rt::launch_whitted_batch(b, m, tree, static_cast<hipStream_t>(stream)));
     }
     return RT_OK;
 }

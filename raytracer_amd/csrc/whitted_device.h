@@ -64,12 +64,16 @@ struct KArgs {
     const DMat* mat;
     const DLight* lights;
     const FGeom* fgeom;        // n_prims records rounded up to a multiple of 4
+    const FGeom* tree;         // sphere tree (sphere_tree.h), n_nodes records; null = not used
+    const FGeom* planes;       // the planes' filter records, original index in v[6] (bits)
+    const int32_t* planes_before;  // [n_prims + 1]: number of planes with a smaller index
     uint8_t* bgr;
     int32_t* hit_id;
     uint32_t* hit_mask;
     uint32_t* spawn_mask;
     unsigned long long* counters;  // 8 x u64, same order as rt_counters
     int32_t n_prims, n_lights;
+    int32_t n_nodes, n_planes;
     int32_t width, height, max_depth;
     int32_t band_rows, band_first, band_step;
     int32_t rows;              // rows of the strip after clipping
@@ -96,11 +100,11 @@ struct KBatch {
     KArgs a[kMaxBatch];
 };
 static_assert(sizeof(KBatch) <= 3072, "kernel argument segment");
-hipError_t launch_whitted_batch(const KBatch& b, int n, hipStream_t stream);
+hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, hipStream_t stream);
 
 // Enqueue the render of one strip on `stream`.  emit = write hit_id/masks (pointers in
 // `a` that are null are skipped), count = add event counts to a.counters.
-hipError_t launch_whitted(const KArgs& a, bool emit, bool count, hipStream_t stream);
+hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, hipStream_t stream);
 
 
 // Enqueue the collision-test hook (rt_debug_intersect).

@@ -241,6 +241,7 @@ struct FilterRay {
     F3 o, d;
     float etb;    // bound on the error of any tca of this ray
     float far2;   // 3 * ePb^2
+    float far2L;  // 8 * eLb^2, eLb bounding the error of L = c - o (bounding-sphere test)
     float en_ray; // eo + 5U|o|_1
     float eden;   // ed + 4U
 };
@@ -257,6 +258,7 @@ __device__ __forceinline__ FilterRay filter_ray(V3 o, V3 d, float scene_p1max) {
     r.etb = __builtin_fmaf(Sb, ed3, eLb);
     const float ePb = __builtin_fmaf(2.0f * U, Sb, 2.0f * r.etb);
     r.far2 = 3.0f * ePb * ePb;
+    r.far2L = 8.0f * eLb * eLb;
     r.en_ray = 6.0f * eo;
     r.eden = 6.0f * U;
     return r;
@@ -278,6 +280,7 @@ __device__ __forceinline__ bool certain_miss(const FRec& g, const FilterRay& r) 
     const float d2 = dotf(P, P);
     return tca < -r.etb || __builtin_fmaf(-2.01f, g.r2, d2) > r.far2;
 }
+
 
 // Plane::TestCollision (src/objects.h:91-102) / Sphere::TestCollision
 // (src/objects.h:124-138) of a broadcast primitive against this lane's ray.
@@ -304,6 +307,108 @@ __device__ __forceinline__ bool test_collision(const DGeom& g, V3 o, V3 d, doubl
         t = (t0 < 0) ? tca + thc : t0;
     }
     return ok;
+}
+
+// ---- sphere tree (large scenes) -------------------------------------------------------
+// Interior nodes of the tree built by sphere_tree.h are bounding spheres (centre C, radius
+// R, both inflated on the host so that the float record contains every member sphere).
+// bound_miss() is true when the reference's test certainly returns nullopt for EVERY
+// sphere below the node:
+//   (A) the ray's line certainly passes the bound at a distance: d2 > 2.01 R^2 + 3 eP^2
+//       gives D_C >= R + 0.2 eP, so the line stays 0.2 eP (about 2e-7 |o|+|c|) clear of
+//       every member, more than the 4.5e-8 |L| by which the reference's rounded d2 can
+//       misjudge a distance; or
+//   (B) the bound is certainly behind the origin: tca < -etb (centre behind) and
+//       |L|^2 > 2.01 R^2 + 8 eL^2 (origin outside by eL): both intersections of the line
+//       with the bound, and with them every point of a member, have a negative parameter.
+__device__ __forceinline__ bool bound_miss(const FRec& g, const FilterRay& r) {
+    const F3 L = f3(g.a0, g.a1, g.a2) - r.o;
+    const float tca = dotf(L, r.d);
+    const F3 P = f3(__builtin_fmaf(-tca, r.d.x, L.x), __builtin_fmaf(-tca, r.d.y, L.y), __builtin_fmaf(-tca, r.d.z, L.z));
+    const bool line = __builtin_fmaf(-2.01f, g.r2, dotf(P, P)) > r.far2;
+    const bool behind = (tca < -r.etb) & (__builtin_fmaf(-2.01f, g.r2, dotf(L, L)) > r.far2L);
+    return line | behind;
+}
+
+// Nearest hit over all objects (src/main.cc:37-47) through the tree.  Objects are met in
+// another order than the container's, so the reference's strict `t < nearest` in
+// container order becomes: smaller t wins, equal t goes to the smaller index.
+template <bool COUNT>
+__device__ __forceinline__ void near_candidate(const FRec& gf, cdata_t geom, int idx, const FilterRay& fr, V3 o, V3 d,
+                                               double& nearest, int& cur) {
+    if (!certain_miss(gf, fr)) {
+        __asm__ volatile("" ::: "memory");
+        const DGeom g = load_geom(geom, idx);
+        double t;
+        const bool hit = test_collision(g, o, d, t);
+        const bool closer = hit && (t < nearest || (t == nearest && idx < cur));
+        nearest = closer ? t : nearest;
+        cur = closer ? idx : cur;
+    }
+}
+template <bool COUNT>
+__device__ __forceinline__ void find_nearest_tree(const KArgs& a, cdata_t geom, V3 o, V3 d, double& nearest, int& cur,
+                                                  uint32_t& c_sph, uint32_t& c_pln) {
+    const FilterRay fr = filter_ray(o, d, a.scene_p1max);
+    if (COUNT) { c_sph += (uint32_t)(a.n_prims - a.n_planes); c_pln += (uint32_t)a.n_planes; }
+    cfdata_t pp = (cfdata_t)(const float*)a.planes;
+    for (int k = 0; k < a.n_planes; ++k, pp += 8) {
+        const FRec gf = load_rec(pp);
+        near_candidate<COUNT>(gf, geom, __float_as_int(pp[6]), fr, o, d, nearest, cur);
+    }
+    const cfdata_t tree = (cfdata_t)(const float*)a.tree;
+    int i = 0;
+    while (i < a.n_nodes) {
+        const FRec gf = load_rec(tree + 8 * i);
+        const int prim = __float_as_int(gf.b1);
+        if (prim >= 0) {  // leaf: the record is the sphere itself
+            near_candidate<COUNT>(gf, geom, prim, fr, o, d, nearest, cur);
+            ++i;
+        } else {
+            const bool maybe = !bound_miss(gf, fr);
+            i = (__builtin_amdgcn_ballot_w64(maybe) != 0ull) ? i + 1 : __float_as_int(gf.b0);
+        }
+    }
+}
+
+// Shadow feeler through the tree (src/objects.h:31-47): the reference stops at the first
+// occluder in container order, i.e. the occluder with the smallest index; `best` tracks it
+// and prunes every node that only holds larger indices.  Returns the index or INT_MAX.
+__device__ __forceinline__ void feeler_candidate(const FRec& gf, cdata_t geom, int idx, const FilterRay& fr, V3 ip, V3 fdir,
+                                                 int cur, int& best, double& best_p) {
+    if (idx != cur && idx < best && !certain_miss(gf, fr)) {
+        __asm__ volatile("" ::: "memory");
+        const DGeom g = load_geom(geom, idx);
+        double p;
+        if (test_collision(g, ip, fdir, p)) {
+            best = idx;
+            best_p = p;
+        }
+    }
+}
+__device__ __forceinline__ int find_occluder_tree(const KArgs& a, cdata_t geom, V3 ip, V3 fdir, int cur, double& best_p) {
+    const FilterRay fr = filter_ray(ip, fdir, a.scene_p1max);
+    int best = 0x7fffffff;
+    cfdata_t pp = (cfdata_t)(const float*)a.planes;
+    for (int k = 0; k < a.n_planes; ++k, pp += 8) {
+        const FRec gf = load_rec(pp);
+        feeler_candidate(gf, geom, __float_as_int(pp[6]), fr, ip, fdir, cur, best, best_p);
+    }
+    const cfdata_t tree = (cfdata_t)(const float*)a.tree;
+    int i = 0;
+    while (i < a.n_nodes) {
+        const cfdata_t rec = tree + 8 * i;
+        const FRec gf = load_rec(rec);
+        const int prim = __float_as_int(gf.b1);
+        if (prim >= 0) {
+            feeler_candidate(gf, geom, prim, fr, ip, fdir, cur, best, best_p);
+            ++i;
+        } else {
+            const bool maybe = (__float_as_int(rec[6]) < best) && !bound_miss(gf, fr);
+            i = (__builtin_amdgcn_ballot_w64(maybe) != 0ull) ? i + 1 : __float_as_int(gf.b0);
+        }
+    }
+    return best;
 }
 
 // The object loops take the scene four records at a time: the float records of a group
@@ -378,7 +483,8 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 // The whole walk of one pixel: lane-private except for the scalar scene loads.
 // (x, k) = column and strip row; `have` is false for lanes without a pixel.
 // MW = mask words kept per lane (0: neither hit_id nor masks are produced).
-template <int MW, bool COUNT>
+// TREE = walk the sphere tree instead of the whole object list (large scenes).
+template <int MW, bool COUNT, bool TREE = false>
 __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const int k, bool have, double* stk,
                                             uint32_t (&cnt)[8]) {
     const cdata_t geom = (cdata_t)(const double*)a.geom;
@@ -419,7 +525,9 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
         // ---- nearest hit, src/main.cc:37-47 ----
         int cur = -1;
         double nearest = __builtin_inf();
-        {
+        if (TREE) {
+            find_nearest_tree<COUNT>(a, geom, o, d, nearest, cur, c_sph, c_pln);
+        } else {
             const FilterRay fr = filter_ray(o, d, a.scene_p1max);
             cfdata_t fp = fgeom;
             cdata_t gp = geom;
@@ -476,25 +584,51 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                 double occl = 1.0;
                 bool open = true;  // no occluder met yet
                 if (COUNT) ++c_feel;
-                const FilterRay ffr = filter_ray(ip, fdir, a.scene_p1max);
-                cfdata_t fp = fgeom;
-                cdata_t gp = geom;
-                int base = 0;
-                for (; base + kGroup <= a.n_prims; base += kGroup, fp += 8 * kGroup, gp += 8 * kGroup) {
-                    if (!__any(open)) break;
-                    const FGroup G = load_group(fp);
-#pragma unroll
-                    for (int j = 0; j < kGroup; ++j)
-                        feeler_slot<COUNT>(G.r[j], gp, j, base + j, true, ffr, ip, fdir, cur, open, occl, c_sph, c_pln,
-                                           c_occ);
-                }
-                if (base < a.n_prims && __any(open)) {
-                    const FGroup G = load_group(fp);
-                    const int rem = a.n_prims - base;
-#pragma unroll
-                    for (int j = 0; j < kGroup - 1; ++j)
-                        feeler_slot<COUNT>(G.r[j], gp, j, base + j, j < rem, ffr, ip, fdir, cur, open, occl, c_sph,
-                                           c_pln, c_occ);
+                if (TREE) {
+                    double best_p = 0.0;
+                    const int best = find_occluder_tree(a, geom, ip, fdir, cur, best_p);
+                    const bool occluded = best != 0x7fffffff;
+                    if (occluded) {
+                        // src/objects.h:40-46, for the occluder with the smallest index
+                        const DGeom* og = a.geom + best;
+                        const bool opl = __double2hiint(og->r2) < 0;
+                        const V3 hp = ip + fdir * best_p;
+                        const V3 no = unit(opl ? mk(og->q[0], og->q[1], og->q[2]) : (hp - mk(og->p[0], og->p[1], og->p[2])));
+                        const double facing = -dot(no, fdir);
+                        const double fres = mix_tenth(1 - facing, 0.0);
+                        occl = (1 - fres) * og->transparency;
+                        if (COUNT) ++c_occ;
+                    }
+                    if (COUNT) {
+                        // the tests the reference makes: objects 0..best (all when open), never `cur`
+                        const bool cur_pl = __double2hiint(gr2) < 0;
+                        const int last = occluded ? best + 1 : a.n_prims;
+                        const int tested = last - ((cur < last) ? 1 : 0);
+                        const int planes = a.planes_before[last] - ((cur_pl && cur < last) ? 1 : 0);
+                        c_pln += (uint32_t)planes;
+                        c_sph += (uint32_t)(tested - planes);
+                    }
+                } else {
+                    const FilterRay ffr = filter_ray(ip, fdir, a.scene_p1max);
+                    cfdata_t fp = fgeom;
+                    cdata_t gp = geom;
+                    int base = 0;
+                    for (; base + kGroup <= a.n_prims; base += kGroup, fp += 8 * kGroup, gp += 8 * kGroup) {
+                        if (!__any(open)) break;
+                        const FGroup G = load_group(fp);
+    #pragma unroll
+                        for (int j = 0; j < kGroup; ++j)
+                            feeler_slot<COUNT>(G.r[j], gp, j, base + j, true, ffr, ip, fdir, cur, open, occl, c_sph, c_pln,
+                                               c_occ);
+                    }
+                    if (base < a.n_prims && __any(open)) {
+                        const FGroup G = load_group(fp);
+                        const int rem = a.n_prims - base;
+    #pragma unroll
+                        for (int j = 0; j < kGroup - 1; ++j)
+                            feeler_slot<COUNT>(G.r[j], gp, j, base + j, j < rem, ffr, ip, fdir, cur, open, occl, c_sph,
+                                               c_pln, c_occ);
+                    }
                 }
                 // src/objects.h:50-60 (light_dir is the same vector as feeler.dir).  The
                 // reference divides by length(normal) * length(light_dir): both are 1 to a

@@ -22,7 +22,7 @@ __device__ __forceinline__ void flush_counters(const KArgs& a, const uint32_t (&
 }
 
 // One wave per 8x8 pixel tile of the strip.
-template <int MW, bool COUNT>
+template <int MW, bool COUNT, bool TREE>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? 4 : 3, 4))) void whitted_kernel(KArgs a) {
     extern __shared__ double lds_stack[];
     const int lane = threadIdx.x & 63;
@@ -34,16 +34,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     const int k = ty * kTile + (lane >> 3);  // row in strip order
     const bool have = (x < a.width) && (k < a.rows);
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    trace_pixel<MW, COUNT>(a, x, k, have, stk, cnt);
+    trace_pixel<MW, COUNT, TREE>(a, x, k, have, stk, cnt);
     flush_counters<COUNT>(a, cnt, lane);
 }
 
-template <int MW, bool COUNT>
-static hipError_t launch_t(const KArgs& a, hipStream_t stream) {
+template <int MW, bool COUNT, bool TREE>
+static hipError_t launch_tt(const KArgs& a, hipStream_t stream) {
     const int bx = (a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     if (bx <= 0 || a.tiles_y <= 0) return hipSuccess;
     const size_t lds = stack_lds_bytes(a.max_depth);
-    hipLaunchKernelGGL((whitted_kernel<MW, COUNT>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
+    hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -51,6 +51,7 @@ static hipError_t launch_t(const KArgs& a, hipStream_t stream) {
 // partition and output), the arguments of all of them travel by value in the kernel
 // argument segment.  Image-only variant; the grid is sized for the largest render, blocks
 // outside a smaller one return at once.
+template <bool TREE>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void whitted_batch_kernel(KBatch b) {
     extern __shared__ double lds_stack[];
@@ -65,10 +66,10 @@ void whitted_batch_kernel(KBatch b) {
     const int k = ty * kTile + (lane >> 3);
     const bool have = (x < a.width) && (k < a.rows);
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    trace_pixel<0, false>(a, x, k, have, stk, cnt);
+    trace_pixel<0, false, TREE>(a, x, k, have, stk, cnt);
 }
 
-hipError_t launch_whitted_batch(const KBatch& b, int n, hipStream_t stream) {
+hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, hipStream_t stream) {
     int bx = 0, by = 0, depth = 0;
     for (int i = 0; i < n; ++i) {
         const KArgs& a = b.a[i];
@@ -77,26 +78,35 @@ hipError_t launch_whitted_batch(const KBatch& b, int n, hipStream_t stream) {
         depth = max(depth, a.max_depth);
     }
     if (n <= 0 || bx <= 0 || by <= 0) return hipSuccess;
-    hipLaunchKernelGGL(whitted_batch_kernel, dim3(bx, by, n), dim3(64 * kWavesPerBlock), stack_lds_bytes(depth), stream,
-                       b);
+    if (tree)
+        hipLaunchKernelGGL(whitted_batch_kernel<true>, dim3(bx, by, n), dim3(64 * kWavesPerBlock),
+                           stack_lds_bytes(depth), stream, b);
+    else
+        hipLaunchKernelGGL(whitted_batch_kernel<false>, dim3(bx, by, n), dim3(64 * kWavesPerBlock),
+                           stack_lds_bytes(depth), stream, b);
     return hipGetLastError();
 }
 
-hipError_t launch_whitted(const KArgs& a, bool emit, bool count, hipStream_t stream) {
+template <int MW, bool COUNT>
+static hipError_t launch_t(const KArgs& a, bool tree, hipStream_t stream) {
+    return tree ? launch_tt<MW, COUNT, true>(a, stream) : launch_tt<MW, COUNT, false>(a, stream);
+}
+
+hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, hipStream_t stream) {
     const int mw = emit ? a.mask_words : 0;
     if (count) {
         switch (mw) {
-            case 0: return launch_t<0, true>(a, stream);
-            case 1: return launch_t<1, true>(a, stream);
-            case 2: return launch_t<2, true>(a, stream);
-            case 4: return launch_t<4, true>(a, stream);
+            case 0: return launch_t<0, true>(a, tree, stream);
+            case 1: return launch_t<1, true>(a, tree, stream);
+            case 2: return launch_t<2, true>(a, tree, stream);
+            case 4: return launch_t<4, true>(a, tree, stream);
         }
     } else {
         switch (mw) {
-            case 0: return launch_t<0, false>(a, stream);
-            case 1: return launch_t<1, false>(a, stream);
-            case 2: return launch_t<2, false>(a, stream);
-            case 4: return launch_t<4, false>(a, stream);
+            case 0: return launch_t<0, false>(a, tree, stream);
+            case 1: return launch_t<1, false>(a, tree, stream);
+            case 2: return launch_t<2, false>(a, tree, stream);
+            case 4: return launch_t<4, false>(a, tree, stream);
         }
     }
     return hipErrorInvalidValue;

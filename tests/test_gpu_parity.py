@@ -140,6 +140,71 @@ def test_plane_box(tracer):
     assert int(ora["counters"]["feelers_occluded"]) > 0
 
 
+def _with_flags(p, flags):
+    q = p.copy()
+    q["flags"] = flags
+    return q
+
+
+@pytest.mark.parametrize("name", ["default", "glass", "spheres64", "plane_only", "one_sphere"])
+def test_sphere_tree_equals_container_order(tracer, name):
+    """The sphere tree (large scenes) against the CPU checker and against the kernel's own
+    container-order loop, on scenes of every size, forced with RT_FLAG_TREE."""
+    if name == "default":
+        prims, lights = scenes.default_scene()
+    elif name == "glass":
+        prims, lights = scenes.glass_scene()
+    elif name == "spheres64":
+        prims, lights = scenes.random_spheres_scene(64, 4, seed=0xBEEF)
+    elif name == "plane_only":
+        prims, lights = scenes.glass_scene(n_spheres=0, n_lights=2)
+    else:
+        prims, lights = scenes.glass_scene(n_spheres=1, n_lights=2)
+    p = abi.make_params(128, 96, 6)
+    tracer.upload_scene(prims, lights)
+    tree = tracer.render(_with_flags(p, abi.RT_FLAG_TREE), want_counters=True)
+    lin = tracer.render(_with_flags(p, abi.RT_FLAG_LINEAR), want_counters=True)
+    ora = oracle_lib.render(prims, lights, p, want_counters=True)
+    assert_parity(tree, ora, f"tree {name}")
+    for k in ("bgr", "hit_id", "hit_mask", "spawn_mask"):
+        assert np.array_equal(tree[k], lin[k]), k
+    assert tree["counters"] == lin["counters"]
+
+
+def test_sphere_tree_ties_and_first_occluder(tracer):
+    """Coincident and nested spheres: equal t at different indices (the smaller index must
+    win, src/main.cc:42 is a strict <) and several occluders on one feeler (the one with the
+    smallest index decides the shadow, src/objects.h:31-47), met by the tree in another
+    order than the container's."""
+    rng = scenes.SplitMix64(0x71E5)
+    prims = [scenes.plane((0, -3, 0), (0, 1, 0), (0.5, 0.5, 0.5), reflectivity=0.2)]
+    base = []
+    for _ in range(20):
+        c = (rng.uniform(-6, 6), rng.uniform(-2, 4), rng.uniform(8, 24))
+        base.append((c, rng.uniform(0.5, 1.6)))
+    order = list(range(20)) * 3          # every sphere three times, different materials
+    for rep, i in enumerate(order):
+        c, r = base[i]
+        tr = 0.0 if (rep // 20) == 1 else rng.uniform(0.3, 0.9)
+        prims.append(scenes.sphere(c, r, (rng.uniform(0.1, 1), rng.uniform(0.1, 1), rng.uniform(0.1, 1)),
+                                   reflectivity=rng.uniform(0, 1), transparency=tr, refraction_index=rng.uniform(1.1, 1.5)))
+    for i in range(0, 20, 3):            # and a smaller sphere inside some of them
+        c, r = base[i]
+        prims.insert(1 + i, scenes.sphere(c, 0.5 * r, (0.9, 0.2, 0.2), transparency=0.5, refraction_index=1.3))
+    lights = [scenes.point_light((1, 1, 1), 0.4, (0, 10, 6)), scenes.point_light((1, 1, 1), 0.3, (8, 6, 30)),
+              scenes.point_light((1, 1, 1), 0.3, (-9, 3, 16))]
+    prims = scenes._stack(prims, abi.PRIM_DTYPE)
+    lights = scenes._stack(lights, abi.LIGHT_DTYPE)
+    assert len(prims) >= 64
+    p = abi.make_params(160, 120, 6)
+    dev, ora = _both(tracer, prims, lights, p)            # the tree is the default here
+    assert_parity(dev, ora, "ties")
+    assert int(ora["counters"]["feelers_occluded"]) > 1000
+    tracer.upload_scene(prims, lights)
+    lin = tracer.render(_with_flags(p, abi.RT_FLAG_LINEAR), want_counters=True)
+    assert lin["counters"] == dev["counters"] and np.array_equal(lin["hit_mask"], dev["hit_mask"])
+
+
 @pytest.mark.parametrize("band_rows,step", [(1, 2), (8, 2), (8, 8), (16, 3), (5, 4)])
 def test_strips_reassemble(tracer, band_rows, step):
     """Rendering the frame as `step` interleaved strips gives the same bytes as the
