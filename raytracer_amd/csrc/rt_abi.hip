@@ -287,11 +287,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
             tsph.push_back(rt::TreeSphere{{s.p[0], s.p[1], s.p[2]}, s.q[0], i});
         }
     }
-    std::vector<rt::FGeom> tree = rt::build_sphere_tree(tsph);
-    for (const rt::FGeom& nd : tree) {  // the filter's per-ray bound must cover the node centres too
-        const float c1 = (std::fabs(nd.v[0]) + std::fabs(nd.v[1]) + std::fabs(nd.v[2])) * 1.0001f;
-        if (c1 > p1max) p1max = c1;
-    }
+    double tree_extent1 = 0.0;
+    std::vector<rt::FGeom> tree = rt::build_sphere_tree(tsph, &tree_extent1);
+    // the filter's per-ray error bound must cover the boxes too
+    if (static_cast<float>(tree_extent1) * 1.0001f > p1max) p1max = static_cast<float>(tree_extent1) * 1.0001f;
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->have_scene = false;
     if (ctx->f_geom) RT_HIP_TRY(ctx, hipFree(ctx->f_geom));

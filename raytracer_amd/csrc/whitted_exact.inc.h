@@ -241,7 +241,8 @@ struct FilterRay {
     F3 o, d;
     float etb;    // bound on the error of any tca of this ray
     float far2;   // 3 * ePb^2
-    float far2L;  // 8 * eLb^2, eLb bounding the error of L = c - o (bounding-sphere test)
+    float ecross; // error bound + clearance of the box test's cross products
+    float ebehind;// error bound of the largest ray parameter over a box
     float en_ray; // eo + 5U|o|_1
     float eden;   // ed + 4U
 };
@@ -258,7 +259,8 @@ __device__ __forceinline__ FilterRay filter_ray(V3 o, V3 d, float scene_p1max) {
     r.etb = __builtin_fmaf(Sb, ed3, eLb);
     const float ePb = __builtin_fmaf(2.0f * U, Sb, 2.0f * r.etb);
     r.far2 = 3.0f * ePb * ePb;
-    r.far2L = 8.0f * eLb * eLb;
+    r.ecross = 32.0f * U * Sb;
+    r.ebehind = __builtin_fmaf(20.0f * U, Sb, r.etb);
     r.en_ray = 6.0f * eo;
     r.eden = 6.0f * U;
     return r;
@@ -310,24 +312,47 @@ __device__ __forceinline__ bool test_collision(const DGeom& g, V3 o, V3 d, doubl
 }
 
 // ---- sphere tree (large scenes) -------------------------------------------------------
-// Interior nodes of the tree built by sphere_tree.h are bounding spheres (centre C, radius
-// R, both inflated on the host so that the float record contains every member sphere).
-// bound_miss() is true when the reference's test certainly returns nullopt for EVERY
-// sphere below the node:
-//   (A) the ray's line certainly passes the bound at a distance: d2 > 2.01 R^2 + 3 eP^2
-//       gives D_C >= R + 0.2 eP, so the line stays 0.2 eP (about 2e-7 |o|+|c|) clear of
-//       every member, more than the 4.5e-8 |L| by which the reference's rounded d2 can
-//       misjudge a distance; or
-//   (B) the bound is certainly behind the origin: tca < -etb (centre behind) and
-//       |L|^2 > 2.01 R^2 + 8 eL^2 (origin outside by eL): both intersections of the line
-//       with the bound, and with them every point of a member, have a negative parameter.
-__device__ __forceinline__ bool bound_miss(const FRec& g, const FilterRay& r) {
-    const F3 L = f3(g.a0, g.a1, g.a2) - r.o;
-    const float tca = dotf(L, r.d);
-    const F3 P = f3(__builtin_fmaf(-tca, r.d.x, L.x), __builtin_fmaf(-tca, r.d.y, L.y), __builtin_fmaf(-tca, r.d.z, L.z));
-    const bool line = __builtin_fmaf(-2.01f, g.r2, dotf(P, P)) > r.far2;
-    const bool behind = (tca < -r.etb) & (__builtin_fmaf(-2.01f, g.r2, dotf(L, L)) > r.far2L);
-    return line | behind;
+// Interior nodes of the tree built by sphere_tree.h are boxes (float centre C, half extents
+// h, rounded outwards on the host so that the box contains every member sphere).
+// box_miss() is true when the reference's test certainly returns nullopt for EVERY sphere
+// below the node.  With m = C - o, Sb >= |o|_1 + |C|_1 + |h|_1, U = 2^-24:
+//   (A) the ray's line passes the box at a distance: for one of the axes n = d x e_k,
+//       |m . n| - sum_j h_j |n_j| > ecross.  In float the left side is off by at most
+//       24 U Sb (m: 2 U Sb; d: 2U; five roundings); ecross = 32 U Sb leaves a clearance of
+//       8 U Sb ~ 5e-7 Sb between line and box, ten times the 4.5e-8 |L| by which the
+//       reference's rounded d2 = L.L - tca^2 can misjudge the distance to a sphere; or
+//   (B) the box is behind the origin: the largest ray parameter over the box,
+//       m . d + sum_j h_j |d_j|, is below -ebehind (its float error is at most
+//       etb + 15 U Sb): every point of every member has a negative parameter.
+struct FNode {
+    float c0, c1, c2;   // centre (box or sphere)
+    float h0, h1, h2;   // half extents; leaf: h0 = radius^2
+    int skip, tag;      // interior: next node when missed, smallest index below; leaf: tag = ~index
+};
+__device__ __forceinline__ FNode load_node(cfdata_t p) {
+    FNode n;
+    n.c0 = p[0]; n.c1 = p[1]; n.c2 = p[2];
+    n.h0 = p[3]; n.h1 = p[4]; n.h2 = p[5];
+    n.skip = __float_as_int(p[6]);
+    n.tag = __float_as_int(p[7]);
+    return n;
+}
+__device__ __forceinline__ FRec leaf_rec(const FNode& n) {
+    FRec g;
+    g.a0 = n.c0; g.a1 = n.c1; g.a2 = n.c2; g.r2 = n.h0;
+    g.b0 = 0.0f; g.b1 = 0.0f;
+    return g;
+}
+__device__ __forceinline__ bool box_miss(const FNode& n, const FilterRay& r) {
+    const F3 m = f3(n.c0, n.c1, n.c2) - r.o;
+    const F3 d = r.d;
+    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+    // separating axes d x e_x, d x e_y, d x e_z
+    const float sx = __builtin_fabsf(__builtin_fmaf(m.y, d.z, -(m.z * d.y))) - __builtin_fmaf(n.h1, az, n.h2 * ay);
+    const float sy = __builtin_fabsf(__builtin_fmaf(m.z, d.x, -(m.x * d.z))) - __builtin_fmaf(n.h2, ax, n.h0 * az);
+    const float sz = __builtin_fabsf(__builtin_fmaf(m.x, d.y, -(m.y * d.x))) - __builtin_fmaf(n.h0, ay, n.h1 * ax);
+    const float tmax = dotf(m, d) + __builtin_fmaf(n.h2, az, __builtin_fmaf(n.h1, ay, n.h0 * ax));
+    return (__builtin_fmaxf(__builtin_fmaxf(sx, sy), sz) > r.ecross) | (tmax < -r.ebehind);
 }
 
 // Nearest hit over all objects (src/main.cc:37-47) through the tree.  Objects are met in
@@ -359,14 +384,13 @@ __device__ __forceinline__ void find_nearest_tree(const KArgs& a, cdata_t geom, 
     const cfdata_t tree = (cfdata_t)(const float*)a.tree;
     int i = 0;
     while (i < a.n_nodes) {
-        const FRec gf = load_rec(tree + 8 * i);
-        const int prim = __float_as_int(gf.b1);
-        if (prim >= 0) {  // leaf: the record is the sphere itself
-            near_candidate<COUNT>(gf, geom, prim, fr, o, d, nearest, cur);
+        const FNode nd = load_node(tree + 8 * i);
+        if (nd.tag < 0) {  // leaf: the record is the sphere itself
+            near_candidate<COUNT>(leaf_rec(nd), geom, ~nd.tag, fr, o, d, nearest, cur);
             ++i;
         } else {
-            const bool maybe = !bound_miss(gf, fr);
-            i = (__builtin_amdgcn_ballot_w64(maybe) != 0ull) ? i + 1 : __float_as_int(gf.b0);
+            const bool maybe = !box_miss(nd, fr);
+            i = (__builtin_amdgcn_ballot_w64(maybe) != 0ull) ? i + 1 : nd.skip;
         }
     }
 }
@@ -397,15 +421,13 @@ __device__ __forceinline__ int find_occluder_tree(const KArgs& a, cdata_t geom, 
     const cfdata_t tree = (cfdata_t)(const float*)a.tree;
     int i = 0;
     while (i < a.n_nodes) {
-        const cfdata_t rec = tree + 8 * i;
-        const FRec gf = load_rec(rec);
-        const int prim = __float_as_int(gf.b1);
-        if (prim >= 0) {
-            feeler_candidate(gf, geom, prim, fr, ip, fdir, cur, best, best_p);
+        const FNode nd = load_node(tree + 8 * i);
+        if (nd.tag < 0) {
+            feeler_candidate(leaf_rec(nd), geom, ~nd.tag, fr, ip, fdir, cur, best, best_p);
             ++i;
         } else {
-            const bool maybe = (__float_as_int(rec[6]) < best) && !bound_miss(gf, fr);
-            i = (__builtin_amdgcn_ballot_w64(maybe) != 0ull) ? i + 1 : __float_as_int(gf.b0);
+            const bool maybe = (nd.tag < best) && !box_miss(nd, fr);
+            i = (__builtin_amdgcn_ballot_w64(maybe) != 0ull) ? i + 1 : nd.skip;
         }
     }
     return best;
