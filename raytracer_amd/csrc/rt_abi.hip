@@ -40,6 +40,8 @@ struct rt_ctx {
     rt::FGeom* f_planes = nullptr;
     int32_t* d_planes_before = nullptr;
     int32_t n_nodes = 0, n_planes = 0;
+    float* d_ltab = nullptr;   // light-anchored line-test constants, n_lights x ltab_stride x 4
+    int32_t ltab_stride = 0;
     // grow-only device staging for rt_render's host outputs
     DevBuf bgr, hit_id, hit_mask, spawn_mask, counters, dbg_in, dbg_t, dbg_hit, dbg_unit;
     hipStream_t stream = nullptr;
@@ -107,6 +109,8 @@ int make_args(rt_ctx* ctx, const rt_params* p, rt::KArgs& a) {
     a.planes_before = ctx->d_planes_before;
     a.n_nodes = ctx->n_nodes;
     a.n_planes = ctx->n_planes;
+    a.ltab = ctx->d_ltab;
+    a.ltab_stride = ctx->ltab_stride;
     a.scene_p1max = ctx->scene_p1max;
     a.n_prims = ctx->n_prims;
     a.n_lights = ctx->n_lights;
@@ -199,6 +203,7 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->f_tree) (void)hipFree(ctx->f_tree);
     if (ctx->f_planes) (void)hipFree(ctx->f_planes);
     if (ctx->d_planes_before) (void)hipFree(ctx->d_planes_before);
+    if (ctx->d_ltab) (void)hipFree(ctx->d_ltab);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -287,6 +292,30 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
             tsph.push_back(rt::TreeSphere{{s.p[0], s.p[1], s.p[2]}, s.q[0], i});
         }
     }
+    // per (light, object) constants of the light-anchored line test (whitted_exact.inc.h)
+    const size_t lstride = fgeom.size();
+    std::vector<float> ltab(static_cast<size_t>(n_lights > 0 ? n_lights : 1) * lstride * 4, 0.0f);
+    for (int li = 0; li < n_lights; ++li) {
+        double l1 = 0.0;
+        for (int c = 0; c < 3; ++c) l1 += std::fabs(lights[li].pos[c]);
+        if (static_cast<float>(l1) * 1.0001f > p1max) p1max = static_cast<float>(l1) * 1.0001f;
+        for (size_t i = 0; i < lstride; ++i) {
+            float* rec = &ltab[(static_cast<size_t>(li) * lstride + i) * 4];
+            rec[3] = -INFINITY;  // planes and padding: never ruled out here
+            if (i >= static_cast<size_t>(n_prims) || prims[i].type != RT_PRIM_SPHERE) continue;
+            double L[3], n2 = 0.0, n1 = 0.0;
+            for (int c = 0; c < 3; ++c) {
+                L[c] = prims[i].p[c] - lights[li].pos[c];
+                n2 += L[c] * L[c];
+                n1 += std::fabs(L[c]);
+                rec[c] = static_cast<float>(L[c]);
+            }
+            const double thr = n2 - prims[i].q[0] * prims[i].q[0] - 20.0 * 6.0e-8 * n1 * n1;
+            float tf = static_cast<float>(thr);
+            tf = std::nextafter(std::nextafter(tf, -INFINITY), -INFINITY);
+            rec[3] = tf;
+        }
+    }
     double tree_extent1 = 0.0;
     std::vector<rt::FGeom> tree = rt::build_sphere_tree(tsph, &tree_extent1);
     // the filter's per-ray error bound must cover the boxes too
@@ -298,8 +327,12 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
     if (ctx->f_tree) RT_HIP_TRY(ctx, hipFree(ctx->f_tree));
     if (ctx->f_planes) RT_HIP_TRY(ctx, hipFree(ctx->f_planes));
     if (ctx->d_planes_before) RT_HIP_TRY(ctx, hipFree(ctx->d_planes_before));
-    ctx->f_tree = nullptr; ctx->f_planes = nullptr; ctx->d_planes_before = nullptr;
+    if (ctx->d_ltab) RT_HIP_TRY(ctx, hipFree(ctx->d_ltab));
+    ctx->f_tree = nullptr; ctx->f_planes = nullptr; ctx->d_planes_before = nullptr; ctx->d_ltab = nullptr;
     ctx->n_nodes = 0; ctx->n_planes = 0;
+    RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_ltab), ltab.size() * sizeof(float)));
+    RT_HIP_TRY(ctx, hipMemcpy(ctx->d_ltab, ltab.data(), ltab.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->ltab_stride = static_cast<int32_t>(lstride);
     if (!tree.empty()) {
         RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->f_tree), tree.size() * sizeof(rt::FGeom)));
         RT_HIP_TRY(ctx, hipMemcpy(ctx->f_tree, tree.data(), tree.size() * sizeof(rt::FGeom), hipMemcpyHostToDevice));

@@ -67,6 +67,8 @@ struct KArgs {
     const FGeom* tree;         // sphere tree (sphere_tree.h), n_nodes records; null = not used
     const FGeom* planes;       // the planes' filter records, original index in v[6] (bits)
     const int32_t* planes_before;  // [n_prims + 1]: number of planes with a smaller index
+    const float* ltab;         // per light, ltab_stride records {c - P (xyz), threshold}: see
+                               // line_miss_from_light(); planes carry threshold -inf
     uint8_t* bgr;
     int32_t* hit_id;
     uint32_t* hit_mask;
@@ -74,6 +76,7 @@ struct KArgs {
     unsigned long long* counters;  // 8 x u64, same order as rt_counters
     int32_t n_prims, n_lights;
     int32_t n_nodes, n_planes;
+    int32_t ltab_stride;       // records per light: n_prims rounded up to a multiple of 4
     int32_t width, height, max_depth;
     int32_t band_rows, band_first, band_step;
     int32_t rows;              // rows of the strip after clipping

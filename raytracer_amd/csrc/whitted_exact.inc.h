@@ -245,12 +245,16 @@ struct FilterRay {
     float ebehind;// error bound of the largest ray parameter over a box
     float en_ray; // eo + 5U|o|_1
     float eden;   // ed + 4U
+    float eray;   // 1e-13 Sb^2: what the reference's own rounding can move a squared distance
 };
-__device__ __forceinline__ FilterRay filter_ray(V3 o, V3 d, float scene_p1max) {
+// Everything but the direction depends on the origin only: the shadow feelers of one hit
+// share it (filter_origin once per hit, set_dir once per light).
+__device__ __forceinline__ void set_dir(FilterRay& r, V3 d) { r.d = f3((float)d.x, (float)d.y, (float)d.z); }
+__device__ __forceinline__ FilterRay filter_origin(V3 o, float scene_p1max) {
     const float U = 6.0e-8f;
     FilterRay r;
     r.o = f3((float)o.x, (float)o.y, (float)o.z);
-    r.d = f3((float)d.x, (float)d.y, (float)d.z);
+    r.d = f3(0.0f, 0.0f, 0.0f);
     const float o1 = l1f(r.o);
     const float eo = U * o1;
     const float ed3 = 5.0f * U;                      // ed + 3U
@@ -263,7 +267,36 @@ __device__ __forceinline__ FilterRay filter_ray(V3 o, V3 d, float scene_p1max) {
     r.ebehind = __builtin_fmaf(20.0f * U, Sb, r.etb);
     r.en_ray = 6.0f * eo;
     r.eden = 6.0f * U;
+    r.eray = 1.0e-13f * Sb * Sb;
     return r;
+}
+__device__ __forceinline__ FilterRay filter_ray(V3 o, V3 d, float scene_p1max) {
+    FilterRay r = filter_origin(o, scene_p1max);
+    set_dir(r, d);
+    return r;
+}
+
+// Light-anchored line test for shadow feelers.  A feeler's line passes through its light
+// P (to within |P - ip| 4e-16, the rounding of the normalisation), so the distance of a
+// sphere's centre c to that line can be taken from the light: with the per-(light, sphere)
+// constant L' = c - P, D^2 = |L'|^2 - (L'.d)^2.  The host stores L' in float and
+// thr = |L'|^2 - r^2 - 20 U |L'|_1^2 rounded down; the float evaluation of
+// thr - (L'.d)^2 is off by at most 14 U |L'|_1^2 (L': U|L'|_1; d: 2U; dot: 3 roundings),
+// so a value above eray proves D^2 > r^2 by more than the reference's own rounding of
+// d2 = L.L - tca^2 (2e-15 |L|^2 <= eray): its test returns nullopt.  Four float operations
+// and a compare per sphere instead of the 15 of the general filter; planes carry
+// thr = -inf and always go on to the general filter.
+struct LRec {
+    float x, y, z, thr;
+};
+__device__ __forceinline__ LRec load_lrec(cfdata_t p) {
+    LRec l;
+    l.x = p[0]; l.y = p[1]; l.z = p[2]; l.thr = p[3];
+    return l;
+}
+__device__ __forceinline__ bool line_miss_from_light(const LRec& l, const FilterRay& r) {
+    const float t = __builtin_fmaf(l.z, r.d.z, __builtin_fmaf(l.y, r.d.y, l.x * r.d.x));
+    return __builtin_fmaf(-t, t, l.thr) > r.eray;
 }
 // True when the reference's test of this ray against the primitive certainly returns
 // nullopt.  ~15 float operations, no division, no square root.
@@ -410,8 +443,8 @@ __device__ __forceinline__ void feeler_candidate(const FRec& gf, cdata_t geom, i
         }
     }
 }
-__device__ __forceinline__ int find_occluder_tree(const KArgs& a, cdata_t geom, V3 ip, V3 fdir, int cur, double& best_p) {
-    const FilterRay fr = filter_ray(ip, fdir, a.scene_p1max);
+__device__ __forceinline__ int find_occluder_tree(const KArgs& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur,
+                                                  double& best_p) {
     int best = 0x7fffffff;
     cfdata_t pp = (cfdata_t)(const float*)a.planes;
     for (int k = 0; k < a.n_planes; ++k, pp += 8) {
@@ -467,17 +500,17 @@ __device__ __forceinline__ void near_slot(const FRec& gf, cdata_t gp, int j, int
 // Slot of a shadow feeler's loop (src/objects.h:31-47): the first occluder in container
 // order decides, the shaded object itself is skipped.
 template <bool COUNT>
-__device__ __forceinline__ void feeler_slot(const FRec& gf, cdata_t gp, int j, int idx, bool valid, const FilterRay& fr,
-                                            V3 ip, V3 fdir, int cur, bool& open, double& occl, uint32_t& c_sph,
-                                            uint32_t& c_pln, uint32_t& c_occ) {
+__device__ __forceinline__ void feeler_slot(const LRec& lr, cfdata_t fp, cdata_t gp, int j, int idx, bool valid,
+                                            const FilterRay& fr, V3 ip, V3 fdir, int cur, bool& open, double& occl,
+                                            uint32_t& c_sph, uint32_t& c_pln, uint32_t& c_occ) {
     const bool tested = valid && open && idx != cur;
-    if (COUNT && tested) { if (__float_as_int(gf.r2) < 0) ++c_pln; else ++c_sph; }
-    const bool maybe = tested && !certain_miss(gf, fr);
-    if (maybe) {
-        __asm__ volatile("" ::: "memory");
+    if (COUNT && tested) { if (lr.thr == -__builtin_inff()) ++c_pln; else ++c_sph; }
+    if (tested && !line_miss_from_light(lr, fr)) {
+        __asm__ volatile("" ::: "memory");  // the rest only for the lanes the line test leaves
+        const FRec gf = load_rec(fp + 8 * j);
         const DGeom g = load_geom(gp, j);
         double p;
-        if (test_collision(g, ip, fdir, p)) {
+        if (!certain_miss(gf, fr) && test_collision(g, ip, fdir, p)) {
             V3 hp = ip + fdir * p;
             V3 no = unit((__double2hiint(g.r2) < 0) ? mk(g.q[0], g.q[1], g.q[2]) : (hp - mk(g.p[0], g.p[1], g.p[2])));
             double facing = -dot(no, fdir);
@@ -512,6 +545,7 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
     const cdata_t geom = (cdata_t)(const double*)a.geom;
     const cdata_t lights = (cdata_t)(const double*)a.lights;
     const cfdata_t fgeom = (cfdata_t)(const float*)a.fgeom;
+    const cfdata_t ltab = (cfdata_t)(const float*)a.ltab;
     const bool inside = have;
     const int band = k / a.band_rows;
     const int y = (a.band_first + band * a.band_step) * a.band_rows + (k - band * a.band_rows);
@@ -600,6 +634,7 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
 
             // ---- Object::Shade, src/objects.h:20-65 ----
             double sr = 0.0, sg = 0.0, sb = 0.0;
+            FilterRay ffr = filter_origin(ip, a.scene_p1max);  // shared by the feelers of this hit
             for (int li = 0; li < a.n_lights; ++li) {
                 const DLight L = load_light(lights, li);
                 const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);  // feeler.dir
@@ -608,7 +643,8 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                 if (COUNT) ++c_feel;
                 if (TREE) {
                     double best_p = 0.0;
-                    const int best = find_occluder_tree(a, geom, ip, fdir, cur, best_p);
+                    set_dir(ffr, fdir);
+                    const int best = find_occluder_tree(a, geom, ffr, ip, fdir, cur, best_p);
                     const bool occluded = best != 0x7fffffff;
                     if (occluded) {
                         // src/objects.h:40-46, for the occluder with the smallest index
@@ -631,25 +667,30 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                         c_sph += (uint32_t)(tested - planes);
                     }
                 } else {
-                    const FilterRay ffr = filter_ray(ip, fdir, a.scene_p1max);
+                    set_dir(ffr, fdir);
+                    cfdata_t lp = ltab + (size_t)li * a.ltab_stride * 4;
                     cfdata_t fp = fgeom;
                     cdata_t gp = geom;
                     int base = 0;
-                    for (; base + kGroup <= a.n_prims; base += kGroup, fp += 8 * kGroup, gp += 8 * kGroup) {
+                    for (; base + kGroup <= a.n_prims; base += kGroup, lp += 4 * kGroup, fp += 8 * kGroup, gp += 8 * kGroup) {
                         if (!__any(open)) break;
-                        const FGroup G = load_group(fp);
-    #pragma unroll
+                        LRec lr[kGroup];
+#pragma unroll
+                        for (int j = 0; j < kGroup; ++j) lr[j] = load_lrec(lp + 4 * j);
+#pragma unroll
                         for (int j = 0; j < kGroup; ++j)
-                            feeler_slot<COUNT>(G.r[j], gp, j, base + j, true, ffr, ip, fdir, cur, open, occl, c_sph, c_pln,
-                                               c_occ);
+                            feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, true, ffr, ip, fdir, cur, open, occl, c_sph,
+                                               c_pln, c_occ);
                     }
                     if (base < a.n_prims && __any(open)) {
-                        const FGroup G = load_group(fp);
                         const int rem = a.n_prims - base;
-    #pragma unroll
+                        LRec lr[kGroup];
+#pragma unroll
+                        for (int j = 0; j < kGroup; ++j) lr[j] = load_lrec(lp + 4 * j);  // padded to whole groups
+#pragma unroll
                         for (int j = 0; j < kGroup - 1; ++j)
-                            feeler_slot<COUNT>(G.r[j], gp, j, base + j, j < rem, ffr, ip, fdir, cur, open, occl, c_sph,
-                                               c_pln, c_occ);
+                            feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, j < rem, ffr, ip, fdir, cur, open, occl,
+                                               c_sph, c_pln, c_occ);
                     }
                 }
                 // src/objects.h:50-60 (light_dir is the same vector as feeler.dir).  The
