@@ -44,6 +44,11 @@ struct rt_ctx {
     int32_t ltab_stride = 0;
     // grow-only device staging for rt_render's host outputs
     DevBuf bgr, hit_id, hit_mask, spawn_mask, counters, dbg_in, dbg_t, dbg_hit, dbg_unit;
+    // global part of the per-lane stacks (deep recursion only).  Grow-only, and a buffer
+    // that was outgrown is kept until rt_destroy: a launch enqueued earlier on another
+    // stream may still be using it.
+    DevBuf gstack;
+    std::vector<void*> gstack_retired;
     hipStream_t stream = nullptr;
 };
 
@@ -88,6 +93,17 @@ int check_params(const rt_params* p) {
 // Fill the kernel arguments for the partition in p.  The camera arithmetic is the
 // ViewFrustum constructor's (src/view_frustum.h:18,28-34), evaluated on the host in
 // double exactly as written there.
+// Make ctx->gstack hold at least `bytes` (0 = nothing to do).
+int reserve_gstack(rt_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->gstack.cap) return RT_OK;
+    void* fresh = nullptr;
+    RT_HIP_TRY(ctx, hipMalloc(&fresh, bytes));
+    if (ctx->gstack.ptr) ctx->gstack_retired.push_back(ctx->gstack.ptr);
+    ctx->gstack.ptr = fresh;
+    ctx->gstack.cap = bytes;
+    return RT_OK;
+}
+
 // The tree pays once a ray has more spheres to test than a walk visits nodes.
 constexpr int kTreeMinSpheres = 32;
 bool use_tree(const rt_ctx* ctx, const rt_params* p) {
@@ -204,6 +220,8 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->f_planes) (void)hipFree(ctx->f_planes);
     if (ctx->d_planes_before) (void)hipFree(ctx->d_planes_before);
     if (ctx->d_ltab) (void)hipFree(ctx->d_ltab);
+    if (ctx->gstack.ptr) (void)hipFree(ctx->gstack.ptr);
+    for (void* q : ctx->gstack_retired) (void)hipFree(q);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -381,6 +399,8 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
     a.counters = reinterpret_cast<unsigned long long*>(d_counters);
     const bool emit = d_hit_id || d_hit_mask || d_spawn_mask;
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((rc = reserve_gstack(ctx, rt::stack_global_bytes(a.max_depth, a.tiles_x, a.tiles_y))) != RT_OK) return rc;
+    a.gstack = static_cast<double*>(ctx->gstack.ptr);
     RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, use_tree(ctx, p), static_cast<hipStream_t>(stream)));
     return RT_OK;
 }
@@ -405,6 +425,7 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
         const int m = (n - base < rt::kMaxBatch) ? n - base : rt::kMaxBatch;
         rt::KBatch b;
         std::memset(&b, 0, sizeof b);
+        size_t goff[rt::kMaxBatch + 1] = {0};
         for (int i = 0; i < m; ++i) {
             int rc = make_args(ctxs[base + i], &params[base + i], b.a[i]);
             if (rc != RT_OK) {
@@ -412,7 +433,13 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
                 return rc;
             }
             b.a[i].bgr = d_bgr[base + i];
+            goff[i + 1] = goff[i] + rt::stack_global_bytes(b.a[i].max_depth, b.a[i].tiles_x, b.a[i].tiles_y);
         }
+        // every render of the launch gets its own part of the first context's workspace
+        int rcg = reserve_gstack(first, goff[m]);
+        if (rcg != RT_OK) return rcg;
+        for (int i = 0; i < m; ++i)
+            b.a[i].gstack = reinterpret_cast<double*>(static_cast<char*>(first->gstack.ptr) + goff[i]);
         RT_HIP_TRY(first, rt::launch_whitted_batch(b, m, tree, static_cast<hipStream_t>(stream)));
     }
     return RT_OK;

@@ -67,6 +67,7 @@ struct KArgs {
     const FGeom* tree;         // sphere tree (sphere_tree.h), n_nodes records; null = not used
     const FGeom* planes;       // the planes' filter records, original index in v[6] (bits)
     const int32_t* planes_before;  // [n_prims + 1]: number of planes with a smaller index
+    double* gstack;            // global part of the stack (stack_global_bytes), null if unused
     const float* ltab;         // per light, ltab_stride records {c - P (xyz), threshold}: see
                                // line_miss_from_light(); planes carry threshold -inf
     uint8_t* bgr;
@@ -88,13 +89,29 @@ struct KArgs {
     float scene_p1max;         // >= |centre|_1 of every sphere (filter bound)
 };
 
-// The walk keeps at most one pending refraction child per tree level 2..max_depth-1.
-// The bottom entry (pushed by the primary hit) lives in registers, the others in LDS:
-// 4 KB per wave and entry, which is what bounds the number of resident waves.
-__host__ __device__ inline int stack_lds_entries(int max_depth) { return max_depth > 3 ? max_depth - 3 : 0; }
+// The walk keeps at most one pending refraction child per tree level 2..max_depth-1, 4 KB
+// per wave and entry.  Entry 0 (pushed by the primary hit) lives in registers, the next
+// kStackLdsEntries in LDS (what bounds the number of resident waves: 8 KB per wave keeps
+// four waves per SIMD), deeper ones in a global-memory workspace with one region per wave
+// of the grid, written and read back by the same wave while it is still in the L2.
+constexpr int kStackLdsEntries = 2;
+__host__ __device__ inline int stack_entries(int max_depth) { return max_depth > 2 ? max_depth - 2 : 0; }
+__host__ __device__ inline int stack_lds_entries(int max_depth) {
+    const int e = stack_entries(max_depth) - 1;
+    return e < 0 ? 0 : (e > kStackLdsEntries ? kStackLdsEntries : e);
+}
+__host__ __device__ inline int stack_global_entries(int max_depth) {
+    const int e = stack_entries(max_depth) - 1 - kStackLdsEntries;
+    return e < 0 ? 0 : e;
+}
 // Bytes of dynamic LDS one block needs for a given max_depth.
 inline size_t stack_lds_bytes(int max_depth) {
     return (size_t)kWavesPerBlock * stack_lds_entries(max_depth) * kStackFields * 64 * sizeof(double);
+}
+// Bytes of global workspace one render needs: a region per wave of its grid.
+inline size_t stack_global_bytes(int max_depth, int tiles_x, int tiles_y) {
+    const size_t bx = (size_t)(tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
+    return bx * kWavesPerBlock * (size_t)tiles_y * stack_global_entries(max_depth) * kStackFields * 64 * sizeof(double);
 }
 
 // Arguments of up to kMaxBatch renders done by one launch (kernel argument segment: 4 KB).

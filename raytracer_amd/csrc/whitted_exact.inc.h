@@ -344,6 +344,35 @@ __device__ __forceinline__ bool test_collision(const DGeom& g, V3 o, V3 d, doubl
     return ok;
 }
 
+// Whether TestCollision returns a value, without the value: what a shadow feeler asks of
+// every object but its first occluder (src/objects.h:38-40).  A sphere needs no square
+// root for that (src/objects.h:126-130 return before it), a plane needs its division.
+__device__ __forceinline__ bool collides(const DGeom& g, V3 o, V3 d) {
+    if (__double2hiint(g.r2) < 0) {
+        double t;
+        return test_collision(g, o, d, t);
+    }
+    const V3 L = mk(g.p[0], g.p[1], g.p[2]) - o;
+    const double tca = dot(L, d);
+    const double d2 = dot(L, L) - tca * tca;
+    return !(tca < 0) & !(d2 > g.r2);
+}
+// Transmission factor of the occluder `og` of the feeler (ip, fdir), src/objects.h:40-46.
+__device__ __forceinline__ double occluder_factor(const DGeom* og, V3 ip, V3 fdir) {
+    DGeom g;
+    g.p[0] = og->p[0]; g.p[1] = og->p[1]; g.p[2] = og->p[2];
+    g.q[0] = og->q[0]; g.q[1] = og->q[1]; g.q[2] = og->q[2];
+    g.r2 = og->r2;
+    g.transparency = og->transparency;
+    double p = 0.0;
+    (void)test_collision(g, ip, fdir, p);  // the same arithmetic as the test that found it
+    const V3 hp = ip + fdir * p;
+    const V3 no = unit((__double2hiint(g.r2) < 0) ? mk(g.q[0], g.q[1], g.q[2]) : (hp - mk(g.p[0], g.p[1], g.p[2])));
+    const double facing = -dot(no, fdir);
+    const double fres = mix_tenth(1 - facing, 0.0);
+    return (1 - fres) * g.transparency;
+}
+
 // ---- sphere tree (large scenes) -------------------------------------------------------
 // Interior nodes of the tree built by sphere_tree.h are boxes (float centre C, half extents
 // h, rounded outwards on the host so that the box contains every member sphere).
@@ -432,31 +461,26 @@ __device__ __forceinline__ void find_nearest_tree(const KArgs& a, cdata_t geom, 
 // occluder in container order, i.e. the occluder with the smallest index; `best` tracks it
 // and prunes every node that only holds larger indices.  Returns the index or INT_MAX.
 __device__ __forceinline__ void feeler_candidate(const FRec& gf, cdata_t geom, int idx, const FilterRay& fr, V3 ip, V3 fdir,
-                                                 int cur, int& best, double& best_p) {
+                                                 int cur, int& best) {
     if (idx != cur && idx < best && !certain_miss(gf, fr)) {
         __asm__ volatile("" ::: "memory");
         const DGeom g = load_geom(geom, idx);
-        double p;
-        if (test_collision(g, ip, fdir, p)) {
-            best = idx;
-            best_p = p;
-        }
+        if (collides(g, ip, fdir)) best = idx;
     }
 }
-__device__ __forceinline__ int find_occluder_tree(const KArgs& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur,
-                                                  double& best_p) {
+__device__ __forceinline__ int find_occluder_tree(const KArgs& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur) {
     int best = 0x7fffffff;
     cfdata_t pp = (cfdata_t)(const float*)a.planes;
     for (int k = 0; k < a.n_planes; ++k, pp += 8) {
         const FRec gf = load_rec(pp);
-        feeler_candidate(gf, geom, __float_as_int(pp[6]), fr, ip, fdir, cur, best, best_p);
+        feeler_candidate(gf, geom, __float_as_int(pp[6]), fr, ip, fdir, cur, best);
     }
     const cfdata_t tree = (cfdata_t)(const float*)a.tree;
     int i = 0;
     while (i < a.n_nodes) {
         const FNode nd = load_node(tree + 8 * i);
         if (nd.tag < 0) {
-            feeler_candidate(leaf_rec(nd), geom, ~nd.tag, fr, ip, fdir, cur, best, best_p);
+            feeler_candidate(leaf_rec(nd), geom, ~nd.tag, fr, ip, fdir, cur, best);
             ++i;
         } else {
             const bool maybe = (nd.tag < best) && !box_miss(nd, fr);
@@ -498,27 +522,19 @@ __device__ __forceinline__ void near_slot(const FRec& gf, cdata_t gp, int j, int
 }
 
 // Slot of a shadow feeler's loop (src/objects.h:31-47): the first occluder in container
-// order decides, the shaded object itself is skipped.
+// order decides, the shaded object itself is skipped.  The slot only records which object
+// that is (`first`, -1 while none); its transmission factor is worked out after the loop.
 template <bool COUNT>
 __device__ __forceinline__ void feeler_slot(const LRec& lr, cfdata_t fp, cdata_t gp, int j, int idx, bool valid,
-                                            const FilterRay& fr, V3 ip, V3 fdir, int cur, bool& open, double& occl,
-                                            uint32_t& c_sph, uint32_t& c_pln, uint32_t& c_occ) {
-    const bool tested = valid && open && idx != cur;
+                                            const FilterRay& fr, V3 ip, V3 fdir, int cur, int& first, uint32_t& c_sph,
+                                            uint32_t& c_pln) {
+    const bool tested = valid && first < 0 && idx != cur;
     if (COUNT && tested) { if (lr.thr == -__builtin_inff()) ++c_pln; else ++c_sph; }
     if (tested && !line_miss_from_light(lr, fr)) {
         __asm__ volatile("" ::: "memory");  // the rest only for the lanes the line test leaves
         const FRec gf = load_rec(fp + 8 * j);
         const DGeom g = load_geom(gp, j);
-        double p;
-        if (!certain_miss(gf, fr) && test_collision(g, ip, fdir, p)) {
-            V3 hp = ip + fdir * p;
-            V3 no = unit((__double2hiint(g.r2) < 0) ? mk(g.q[0], g.q[1], g.q[2]) : (hp - mk(g.p[0], g.p[1], g.p[2])));
-            double facing = -dot(no, fdir);
-            double fres = mix_tenth(1 - facing, 0.0);
-            occl = (1 - fres) * g.transparency;
-            open = false;
-            if (COUNT) ++c_occ;
-        }
+        if (!certain_miss(gf, fr) && collides(g, ip, fdir)) first = idx;
     }
 }
 
@@ -539,9 +555,11 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 // (x, k) = column and strip row; `have` is false for lanes without a pixel.
 // MW = mask words kept per lane (0: neither hit_id nor masks are produced).
 // TREE = walk the sphere tree instead of the whole object list (large scenes).
-template <int MW, bool COUNT, bool TREE = false>
+// DEEP = the stack may reach its global-memory part (max_depth > 3 + kStackLdsEntries);
+//        without it that code is left out, which the register allocation needs.
+template <int MW, bool COUNT, bool TREE, bool DEEP>
 __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const int k, bool have, double* stk,
-                                            uint32_t (&cnt)[8]) {
+                                            double* gstk, const int lane, uint32_t (&cnt)[8]) {
     const cdata_t geom = (cdata_t)(const double*)a.geom;
     const cdata_t lights = (cdata_t)(const double*)a.lights;
     const cfdata_t fgeom = (cfdata_t)(const float*)a.fgeom;
@@ -639,59 +657,49 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                 const DLight L = load_light(lights, li);
                 const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);  // feeler.dir
                 double occl = 1.0;
-                bool open = true;  // no occluder met yet
                 if (COUNT) ++c_feel;
+                int first = -1;  // index of the first occluder in container order
+                set_dir(ffr, fdir);
                 if (TREE) {
-                    double best_p = 0.0;
-                    set_dir(ffr, fdir);
-                    const int best = find_occluder_tree(a, geom, ffr, ip, fdir, cur, best_p);
-                    const bool occluded = best != 0x7fffffff;
-                    if (occluded) {
-                        // src/objects.h:40-46, for the occluder with the smallest index
-                        const DGeom* og = a.geom + best;
-                        const bool opl = __double2hiint(og->r2) < 0;
-                        const V3 hp = ip + fdir * best_p;
-                        const V3 no = unit(opl ? mk(og->q[0], og->q[1], og->q[2]) : (hp - mk(og->p[0], og->p[1], og->p[2])));
-                        const double facing = -dot(no, fdir);
-                        const double fres = mix_tenth(1 - facing, 0.0);
-                        occl = (1 - fres) * og->transparency;
-                        if (COUNT) ++c_occ;
-                    }
+                    const int best = find_occluder_tree(a, geom, ffr, ip, fdir, cur);
+                    first = (best != 0x7fffffff) ? best : -1;
                     if (COUNT) {
-                        // the tests the reference makes: objects 0..best (all when open), never `cur`
+                        // the tests the reference makes: objects 0..first (all when open), never `cur`
                         const bool cur_pl = __double2hiint(gr2) < 0;
-                        const int last = occluded ? best + 1 : a.n_prims;
+                        const int last = (first >= 0) ? first + 1 : a.n_prims;
                         const int tested = last - ((cur < last) ? 1 : 0);
                         const int planes = a.planes_before[last] - ((cur_pl && cur < last) ? 1 : 0);
                         c_pln += (uint32_t)planes;
                         c_sph += (uint32_t)(tested - planes);
                     }
                 } else {
-                    set_dir(ffr, fdir);
                     cfdata_t lp = ltab + (size_t)li * a.ltab_stride * 4;
                     cfdata_t fp = fgeom;
                     cdata_t gp = geom;
                     int base = 0;
                     for (; base + kGroup <= a.n_prims; base += kGroup, lp += 4 * kGroup, fp += 8 * kGroup, gp += 8 * kGroup) {
-                        if (!__any(open)) break;
+                        if (!__any(first < 0)) break;
                         LRec lr[kGroup];
 #pragma unroll
                         for (int j = 0; j < kGroup; ++j) lr[j] = load_lrec(lp + 4 * j);
 #pragma unroll
                         for (int j = 0; j < kGroup; ++j)
-                            feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, true, ffr, ip, fdir, cur, open, occl, c_sph,
-                                               c_pln, c_occ);
+                            feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, true, ffr, ip, fdir, cur, first, c_sph, c_pln);
                     }
-                    if (base < a.n_prims && __any(open)) {
+                    if (base < a.n_prims && __any(first < 0)) {
                         const int rem = a.n_prims - base;
                         LRec lr[kGroup];
 #pragma unroll
                         for (int j = 0; j < kGroup; ++j) lr[j] = load_lrec(lp + 4 * j);  // padded to whole groups
 #pragma unroll
                         for (int j = 0; j < kGroup - 1; ++j)
-                            feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, j < rem, ffr, ip, fdir, cur, open, occl,
-                                               c_sph, c_pln, c_occ);
+                            feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, j < rem, ffr, ip, fdir, cur, first, c_sph,
+                                               c_pln);
                     }
+                }
+                if (first >= 0) {
+                    occl = occluder_factor(a.geom + first, ip, fdir);
+                    if (COUNT) ++c_occ;
                 }
                 // src/objects.h:50-60 (light_dir is the same vector as feeler.dir).  The
                 // reference divides by length(normal) * length(light_dir): both are 1 to a
@@ -740,9 +748,15 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
 #pragma unroll
                         for (int f = 0; f < kStackFields; ++f) bottom[f] = ent[f];
                     } else {
-                        double* e = stk + (size_t)(sp - 1) * kStackFields * 64;
+                        if (!DEEP || sp <= kStackLdsEntries) {
+                            double* e = stk + (size_t)(sp - 1) * kStackFields * 64;
 #pragma unroll
-                        for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
+                            for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
+                        } else {
+                            double* e = gstk + (size_t)(sp - 1 - kStackLdsEntries) * kStackFields * 64 + lane;
+#pragma unroll
+                            for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
+                        }
                     }
                     ++sp;
                 }
@@ -764,9 +778,15 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
 #pragma unroll
                     for (int f = 0; f < kStackFields; ++f) ent[f] = bottom[f];
                 } else {
-                    const double* e = stk + (size_t)(sp - 1) * kStackFields * 64;
+                    if (!DEEP || sp <= kStackLdsEntries) {
+                        const double* e = stk + (size_t)(sp - 1) * kStackFields * 64;
 #pragma unroll
-                    for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
+                        for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
+                    } else {
+                        const double* e = gstk + (size_t)(sp - 1 - kStackLdsEntries) * kStackFields * 64 + lane;
+#pragma unroll
+                        for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
+                    }
                 }
                 o = mk(ent[0], ent[1], ent[2]);
                 d = mk(ent[3], ent[4], ent[5]);

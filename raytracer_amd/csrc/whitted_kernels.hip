@@ -21,29 +21,38 @@ __device__ __forceinline__ void flush_counters(const KArgs& a, const uint32_t (&
     }
 }
 
+// This wave's region of the global stack workspace (lane-major like the LDS part).
+// (tx, ty must be wave-uniform values: the result then stays in scalar registers.)
+__device__ __forceinline__ double* wave_gstack(const KArgs& a, int tx, int ty) {
+    const size_t waves_x = (size_t)((a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock) * kWavesPerBlock;
+    const size_t w = (size_t)ty * waves_x + tx;
+    return a.gstack + w * stack_global_entries(a.max_depth) * kStackFields * 64;
+}
+
 // One wave per 8x8 pixel tile of the strip.
-template <int MW, bool COUNT, bool TREE>
+template <int MW, bool COUNT, bool TREE, bool DEEP>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? 4 : 3, 4))) void whitted_kernel(KArgs a) {
     extern __shared__ double lds_stack[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* stk = lds_stack + (size_t)wave * stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
     const int tx = blockIdx.x * kWavesPerBlock + wave;  // a block = 4 tiles side by side
     const int ty = blockIdx.y;
     const int x = tx * kTile + (lane & 7);
     const int k = ty * kTile + (lane >> 3);  // row in strip order
     const bool have = (x < a.width) && (k < a.rows);
+    double* gstk = wave_gstack(a, tx, ty);
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    trace_pixel<MW, COUNT, TREE>(a, x, k, have, stk, cnt);
+    trace_pixel<MW, COUNT, TREE, DEEP>(a, x, k, have, stk, gstk, lane, cnt);
     flush_counters<COUNT>(a, cnt, lane);
 }
 
-template <int MW, bool COUNT, bool TREE>
-static hipError_t launch_tt(const KArgs& a, hipStream_t stream) {
+template <int MW, bool COUNT, bool TREE, bool DEEP>
+static hipError_t launch_ttd(const KArgs& a, hipStream_t stream) {
     const int bx = (a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     if (bx <= 0 || a.tiles_y <= 0) return hipSuccess;
     const size_t lds = stack_lds_bytes(a.max_depth);
-    hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
+    hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -51,22 +60,23 @@ static hipError_t launch_tt(const KArgs& a, hipStream_t stream) {
 // partition and output), the arguments of all of them travel by value in the kernel
 // argument segment.  Image-only variant; the grid is sized for the largest render, blocks
 // outside a smaller one return at once.
-template <bool TREE>
+template <bool TREE, bool DEEP>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void whitted_batch_kernel(KBatch b) {
     extern __shared__ double lds_stack[];
     const KArgs& a = b.a[blockIdx.z];
     if ((int)blockIdx.y >= a.tiles_y || (int)(blockIdx.x * kWavesPerBlock) >= a.tiles_x) return;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* stk = lds_stack + (size_t)wave * stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
     const int tx = blockIdx.x * kWavesPerBlock + wave;
     const int ty = blockIdx.y;
     const int x = tx * kTile + (lane & 7);
     const int k = ty * kTile + (lane >> 3);
     const bool have = (x < a.width) && (k < a.rows);
+    double* gstk = wave_gstack(a, tx, ty);
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    trace_pixel<0, false, TREE>(a, x, k, have, stk, cnt);
+    trace_pixel<0, false, TREE, DEEP>(a, x, k, have, stk, gstk, lane, cnt);
 }
 
 hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, hipStream_t stream) {
@@ -78,13 +88,22 @@ hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, hipStream_t s
         depth = max(depth, a.max_depth);
     }
     if (n <= 0 || bx <= 0 || by <= 0) return hipSuccess;
-    if (tree)
-        hipLaunchKernelGGL(whitted_batch_kernel<true>, dim3(bx, by, n), dim3(64 * kWavesPerBlock),
-                           stack_lds_bytes(depth), stream, b);
-    else
-        hipLaunchKernelGGL(whitted_batch_kernel<false>, dim3(bx, by, n), dim3(64 * kWavesPerBlock),
-                           stack_lds_bytes(depth), stream, b);
+    const dim3 grid(bx, by, n), block(64 * kWavesPerBlock);
+    const size_t lds = stack_lds_bytes(depth);
+    const bool deep = stack_global_entries(depth) > 0;
+    if (tree && deep) hipLaunchKernelGGL((whitted_batch_kernel<true, true>), grid, block, lds, stream, b);
+    else if (tree) hipLaunchKernelGGL((whitted_batch_kernel<true, false>), grid, block, lds, stream, b);
+    else if (deep) hipLaunchKernelGGL((whitted_batch_kernel<false, true>), grid, block, lds, stream, b);
+    else hipLaunchKernelGGL((whitted_batch_kernel<false, false>), grid, block, lds, stream, b);
     return hipGetLastError();
+}
+
+// Only the image-only kernel exists without the deep-stack code; the others always carry it.
+template <int MW, bool COUNT, bool TREE>
+static hipError_t launch_tt(const KArgs& a, hipStream_t stream) {
+    if (MW == 0 && !COUNT && stack_global_entries(a.max_depth) == 0)
+        return launch_ttd<MW, COUNT, TREE, !(MW == 0 && !COUNT)>(a, stream);
+    return launch_ttd<MW, COUNT, TREE, true>(a, stream);
 }
 
 template <int MW, bool COUNT>
