@@ -26,8 +26,10 @@ timed steps (max over ranks), with scene and buffers resident in HBM before the 
 starts.  Rays = TraceRay invocations that pass the depth stop, counted by the kernel's
 counter variant in an untimed launch (and equal to the CPU checker's count).
 
-roofline: the path is bound by the FP32/FP64 vector ALUs, not by MFMA or HBM, so `bound`
-is "valu" and `peak` the gfx950 FP32 vector peak (157.3 TFLOP/s).  achieved = algorithmic
+roofline: the path is bound by the vector ALUs, not by MFMA or HBM, so `bound` is "valu".
+`peak` is the gfx950 FP64 vector peak, 78.6 TFLOP/s (256 CUs x 4 SIMDs x 16 lanes x 2 flop x
+2.4 GHz; the path computes in f64 - `dtype`); `frac_of_fp32_packed_peak` gives the same
+figure against the 157.3 TFLOP/s packed-FP32 vector peak.  achieved = algorithmic
 flops of one launch / mean kernel time measured with HIP events around every timed
 launch, on the stream the kernel runs on.  Algorithmic flops = event counts x a fixed
 cost table (see FLOP_TABLE).  `traffic` is the HBM bytes per launch taken from the PMC
@@ -53,7 +55,8 @@ if ROOT not in sys.path:
 
 from raytracer_amd import abi, scenes, strips  # noqa: E402
 
-PEAK_FP32_VALU_TFLOPS = 157.3
+PEAK_FP64_VALU_TFLOPS = 78.6
+PEAK_FP32_PACKED_VALU_TFLOPS = 157.3
 
 # Flops per event (mul/add/sub/div/sqrt = 1 each), the reference's arithmetic as written.
 FLOP_TABLE = {
@@ -370,9 +373,10 @@ def main():
             "roofline": {
                 "bound": "valu",
                 "achieved": achieved,
-                "peak": PEAK_FP32_VALU_TFLOPS,
+                "peak": PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                "frac": achieved / PEAK_FP64_VALU_TFLOPS,
+                "frac_of_fp32_packed_peak": achieved / PEAK_FP32_PACKED_VALU_TFLOPS,
                 "traffic": _traffic_bytes(args.workload) if world == 1 else None,
                 "kernel": "whitted_batch_kernel" if mode == "strips" else "whitted_kernel<0,false>",
                 "kernel_ms": kernel_ms,

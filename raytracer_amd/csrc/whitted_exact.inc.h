@@ -347,30 +347,38 @@ __device__ __forceinline__ bool test_collision(const DGeom& g, V3 o, V3 d, doubl
 // Whether TestCollision returns a value, without the value: what a shadow feeler asks of
 // every object but its first occluder (src/objects.h:38-40).  A sphere needs no square
 // root for that (src/objects.h:126-130 return before it), a plane needs its division.
-__device__ __forceinline__ bool collides(const DGeom& g, V3 o, V3 d) {
+// On a hit (pa, pb) keep what the value follows from: a plane's t and -1, or a sphere's
+// tca and r2 - d2 >= 0 (collision_value() finishes the arithmetic of src/objects.h:131-137).
+__device__ __forceinline__ bool collides(const DGeom& g, V3 o, V3 d, double& pa, double& pb) {
     if (__double2hiint(g.r2) < 0) {
-        double t;
-        return test_collision(g, o, d, t);
+        double t = 0.0;
+        const bool hit = test_collision(g, o, d, t);
+        pa = hit ? t : pa;
+        pb = hit ? -1.0 : pb;
+        return hit;
     }
     const V3 L = mk(g.p[0], g.p[1], g.p[2]) - o;
     const double tca = dot(L, d);
     const double d2 = dot(L, L) - tca * tca;
-    return !(tca < 0) & !(d2 > g.r2);
+    const bool hit = !(tca < 0) & !(d2 > g.r2);
+    pa = hit ? tca : pa;
+    pb = hit ? g.r2 - d2 : pb;
+    return hit;
+}
+__device__ __forceinline__ double collision_value(double pa, double pb) {
+    const double thc = __builtin_sqrt(pb);   // NaN for a plane's -1, not used then
+    const double t0 = pa - thc;
+    const double ts = (t0 < 0) ? pa + thc : t0;
+    return (pb < 0) ? pa : ts;
 }
 // Transmission factor of the occluder `og` of the feeler (ip, fdir), src/objects.h:40-46.
-__device__ __forceinline__ double occluder_factor(const DGeom* og, V3 ip, V3 fdir) {
-    DGeom g;
-    g.p[0] = og->p[0]; g.p[1] = og->p[1]; g.p[2] = og->p[2];
-    g.q[0] = og->q[0]; g.q[1] = og->q[1]; g.q[2] = og->q[2];
-    g.r2 = og->r2;
-    g.transparency = og->transparency;
-    double p = 0.0;
-    (void)test_collision(g, ip, fdir, p);  // the same arithmetic as the test that found it
+__device__ __forceinline__ double occluder_factor(const DGeom* og, V3 ip, V3 fdir, double pa, double pb) {
+    const double p = collision_value(pa, pb);
     const V3 hp = ip + fdir * p;
-    const V3 no = unit((__double2hiint(g.r2) < 0) ? mk(g.q[0], g.q[1], g.q[2]) : (hp - mk(g.p[0], g.p[1], g.p[2])));
+    const V3 no = unit((pb < 0) ? mk(og->q[0], og->q[1], og->q[2]) : (hp - mk(og->p[0], og->p[1], og->p[2])));
     const double facing = -dot(no, fdir);
     const double fres = mix_tenth(1 - facing, 0.0);
-    return (1 - fres) * g.transparency;
+    return (1 - fres) * og->transparency;
 }
 
 // ---- sphere tree (large scenes) -------------------------------------------------------
@@ -461,26 +469,27 @@ __device__ __forceinline__ void find_nearest_tree(const KArgs& a, cdata_t geom, 
 // occluder in container order, i.e. the occluder with the smallest index; `best` tracks it
 // and prunes every node that only holds larger indices.  Returns the index or INT_MAX.
 __device__ __forceinline__ void feeler_candidate(const FRec& gf, cdata_t geom, int idx, const FilterRay& fr, V3 ip, V3 fdir,
-                                                 int cur, int& best) {
+                                                 int cur, int& best, double& pa, double& pb) {
     if (idx != cur && idx < best && !certain_miss(gf, fr)) {
         __asm__ volatile("" ::: "memory");
         const DGeom g = load_geom(geom, idx);
-        if (collides(g, ip, fdir)) best = idx;
+        if (collides(g, ip, fdir, pa, pb)) best = idx;
     }
 }
-__device__ __forceinline__ int find_occluder_tree(const KArgs& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur) {
+__device__ __forceinline__ int find_occluder_tree(const KArgs& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur,
+                                                  double& pa, double& pb) {
     int best = 0x7fffffff;
     cfdata_t pp = (cfdata_t)(const float*)a.planes;
     for (int k = 0; k < a.n_planes; ++k, pp += 8) {
         const FRec gf = load_rec(pp);
-        feeler_candidate(gf, geom, __float_as_int(pp[6]), fr, ip, fdir, cur, best);
+        feeler_candidate(gf, geom, __float_as_int(pp[6]), fr, ip, fdir, cur, best, pa, pb);
     }
     const cfdata_t tree = (cfdata_t)(const float*)a.tree;
     int i = 0;
     while (i < a.n_nodes) {
         const FNode nd = load_node(tree + 8 * i);
         if (nd.tag < 0) {
-            feeler_candidate(leaf_rec(nd), geom, ~nd.tag, fr, ip, fdir, cur, best);
+            feeler_candidate(leaf_rec(nd), geom, ~nd.tag, fr, ip, fdir, cur, best, pa, pb);
             ++i;
         } else {
             const bool maybe = (nd.tag < best) && !box_miss(nd, fr);
@@ -522,19 +531,28 @@ __device__ __forceinline__ void near_slot(const FRec& gf, cdata_t gp, int j, int
 }
 
 // Slot of a shadow feeler's loop (src/objects.h:31-47): the first occluder in container
-// order decides, the shaded object itself is skipped.  The slot only records which object
-// that is (`first`, -1 while none); its transmission factor is worked out after the loop.
+// order decides, the shaded object itself is skipped.  `first` = its index (-1 while none),
+// `factor` = its transmission factor.
 template <bool COUNT>
 __device__ __forceinline__ void feeler_slot(const LRec& lr, cfdata_t fp, cdata_t gp, int j, int idx, bool valid,
-                                            const FilterRay& fr, V3 ip, V3 fdir, int cur, int& first, uint32_t& c_sph,
-                                            uint32_t& c_pln) {
+                                            const FilterRay& fr, V3 ip, V3 fdir, int cur, int& first, double& factor,
+                                            uint32_t& c_sph, uint32_t& c_pln) {
     const bool tested = valid && first < 0 && idx != cur;
     if (COUNT && tested) { if (lr.thr == -__builtin_inff()) ++c_pln; else ++c_sph; }
     if (tested && !line_miss_from_light(lr, fr)) {
         __asm__ volatile("" ::: "memory");  // the rest only for the lanes the line test leaves
         const FRec gf = load_rec(fp + 8 * j);
         const DGeom g = load_geom(gp, j);
-        if (!certain_miss(gf, fr) && collides(g, ip, fdir)) first = idx;
+        double p;
+        if (!certain_miss(gf, fr) && test_collision(g, ip, fdir, p)) {
+            // src/objects.h:40-46, here with the object's record still in scalar registers
+            const V3 hp = ip + fdir * p;
+            const V3 no = unit((__double2hiint(g.r2) < 0) ? mk(g.q[0], g.q[1], g.q[2]) : (hp - mk(g.p[0], g.p[1], g.p[2])));
+            const double facing = -dot(no, fdir);
+            const double fres = mix_tenth(1 - facing, 0.0);
+            factor = (1 - fres) * g.transparency;
+            first = idx;
+        }
     }
 }
 
@@ -661,8 +679,12 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                 int first = -1;  // index of the first occluder in container order
                 set_dir(ffr, fdir);
                 if (TREE) {
-                    const int best = find_occluder_tree(a, geom, ffr, ip, fdir, cur);
+                    // the walk meets occluders in any order: it only keeps the one with the
+                    // smallest index, whose factor is worked out afterwards
+                    double pa = 0.0, pb = 0.0;  // see collides()
+                    const int best = find_occluder_tree(a, geom, ffr, ip, fdir, cur, pa, pb);
                     first = (best != 0x7fffffff) ? best : -1;
+                    if (first >= 0) occl = occluder_factor(a.geom + first, ip, fdir, pa, pb);
                     if (COUNT) {
                         // the tests the reference makes: objects 0..first (all when open), never `cur`
                         const bool cur_pl = __double2hiint(gr2) < 0;
@@ -684,7 +706,8 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                         for (int j = 0; j < kGroup; ++j) lr[j] = load_lrec(lp + 4 * j);
 #pragma unroll
                         for (int j = 0; j < kGroup; ++j)
-                            feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, true, ffr, ip, fdir, cur, first, c_sph, c_pln);
+                            feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, true, ffr, ip, fdir, cur, first, occl, c_sph,
+                                               c_pln);
                     }
                     if (base < a.n_prims && __any(first < 0)) {
                         const int rem = a.n_prims - base;
@@ -693,14 +716,11 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                         for (int j = 0; j < kGroup; ++j) lr[j] = load_lrec(lp + 4 * j);  // padded to whole groups
 #pragma unroll
                         for (int j = 0; j < kGroup - 1; ++j)
-                            feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, j < rem, ffr, ip, fdir, cur, first, c_sph,
-                                               c_pln);
+                            feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, j < rem, ffr, ip, fdir, cur, first, occl,
+                                               c_sph, c_pln);
                     }
                 }
-                if (first >= 0) {
-                    occl = occluder_factor(a.geom + first, ip, fdir);
-                    if (COUNT) ++c_occ;
-                }
+                if (COUNT && first >= 0) ++c_occ;
                 // src/objects.h:50-60 (light_dir is the same vector as feeler.dir).  The
                 // reference divides by length(normal) * length(light_dir): both are 1 to a
                 // few 2^-53, so the quotient is left out (colour only, below 1e-15).
