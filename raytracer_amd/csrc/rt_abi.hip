@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -44,10 +45,11 @@ struct rt_ctx {
     int32_t ltab_stride = 0;
     // grow-only device staging for rt_render's host outputs
     DevBuf bgr, hit_id, hit_mask, spawn_mask, counters, dbg_in, dbg_t, dbg_hit, dbg_unit;
-    // global part of the per-lane stacks (deep recursion only).  Grow-only, and a buffer
-    // that was outgrown is kept until rt_destroy: a launch enqueued earlier on another
-    // stream may still be using it.
-    DevBuf gstack;
+    // global part of the per-lane stacks (deep recursion only): one workspace per stream
+    // the context has rendered on, since launches on one stream run one after the other
+    // but launches on different streams may overlap.  Grow-only; a buffer that was
+    // outgrown is kept until rt_destroy (an earlier launch may still be using it).
+    std::map<void*, DevBuf> gstack;
     std::vector<void*> gstack_retired;
     hipStream_t stream = nullptr;
 };
@@ -93,14 +95,19 @@ int check_params(const rt_params* p) {
 // Fill the kernel arguments for the partition in p.  The camera arithmetic is the
 // ViewFrustum constructor's (src/view_frustum.h:18,28-34), evaluated on the host in
 // double exactly as written there.
-// Make ctx->gstack hold at least `bytes` (0 = nothing to do).
-int reserve_gstack(rt_ctx* ctx, size_t bytes) {
-    if (bytes <= ctx->gstack.cap) return RT_OK;
-    void* fresh = nullptr;
-    RT_HIP_TRY(ctx, hipMalloc(&fresh, bytes));
-    if (ctx->gstack.ptr) ctx->gstack_retired.push_back(ctx->gstack.ptr);
-    ctx->gstack.ptr = fresh;
-    ctx->gstack.cap = bytes;
+// The stack workspace of `stream`, at least `bytes` large (*out = null when bytes is 0).
+int reserve_gstack(rt_ctx* ctx, void* stream, size_t bytes, void** out) {
+    *out = nullptr;
+    if (bytes == 0) return RT_OK;
+    DevBuf& b = ctx->gstack[stream];
+    if (bytes > b.cap) {
+        void* fresh = nullptr;
+        RT_HIP_TRY(ctx, hipMalloc(&fresh, bytes));
+        if (b.ptr) ctx->gstack_retired.push_back(b.ptr);
+        b.ptr = fresh;
+        b.cap = bytes;
+    }
+    *out = b.ptr;
     return RT_OK;
 }
 
@@ -220,7 +227,8 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->f_planes) (void)hipFree(ctx->f_planes);
     if (ctx->d_planes_before) (void)hipFree(ctx->d_planes_before);
     if (ctx->d_ltab) (void)hipFree(ctx->d_ltab);
-    if (ctx->gstack.ptr) (void)hipFree(ctx->gstack.ptr);
+    for (auto& kv : ctx->gstack)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     for (void* q : ctx->gstack_retired) (void)hipFree(q);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -399,8 +407,10 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
     a.counters = reinterpret_cast<unsigned long long*>(d_counters);
     const bool emit = d_hit_id || d_hit_mask || d_spawn_mask;
     RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if ((rc = reserve_gstack(ctx, rt::stack_global_bytes(a.max_depth, a.tiles_x, a.tiles_y))) != RT_OK) return rc;
-    a.gstack = static_cast<double*>(ctx->gstack.ptr);
+    void* ws = nullptr;
+    if ((rc = reserve_gstack(ctx, stream, rt::stack_global_bytes(a.max_depth, a.tiles_x, a.tiles_y), &ws)) != RT_OK)
+        return rc;
+    a.gstack = static_cast<double*>(ws);
     RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, use_tree(ctx, p), static_cast<hipStream_t>(stream)));
     return RT_OK;
 }
@@ -436,10 +446,11 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
             goff[i + 1] = goff[i] + rt::stack_global_bytes(b.a[i].max_depth, b.a[i].tiles_x, b.a[i].tiles_y);
         }
         // every render of the launch gets its own part of the first context's workspace
-        int rcg = reserve_gstack(first, goff[m]);
+        void* ws = nullptr;
+        int rcg = reserve_gstack(first, stream, goff[m], &ws);
         if (rcg != RT_OK) return rcg;
         for (int i = 0; i < m; ++i)
-            b.a[i].gstack = reinterpret_cast<double*>(static_cast<char*>(first->gstack.ptr) + goff[i]);
+            b.a[i].gstack = ws ? reinterpret_cast<double*>(static_cast<char*>(ws) + goff[i]) : nullptr;
         RT_HIP_TRY(first, rt::launch_whitted_batch(b, m, tree, static_cast<hipStream_t>(stream)));
     }
     return RT_OK;

@@ -140,3 +140,23 @@ def test_batched_launch_on_gpu(tracer):
     slots = [x.submit() for _ in range(3)]
     assert np.array_equal(x.frame(slots[-1]).cpu().numpy(), want)
     other.close()
+
+
+def test_deep_renders_on_two_streams(tracer):
+    """Depth-8 renders keep part of their per-lane stacks in a global workspace; two of them
+    enqueued on different streams of one context may overlap and must not share it."""
+    import torch
+
+    prims, lights = scenes.glass_scene()
+    tracer.upload_scene(prims, lights)
+    p = abi.make_params(320, 200, 8)
+    want = tracer.render(p, want_ids=False, want_masks=False)["bgr"]
+    dev = torch.device("cuda", 0)
+    outs = [torch.zeros((200, 320, 3), dtype=torch.uint8, device=dev) for _ in range(4)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for i, o in enumerate(outs):
+        tracer.render_device(p, streams[i & 1].cuda_stream, o.data_ptr())
+    for s in streams:
+        s.synchronize()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), want)
