@@ -1,38 +1,22 @@
-// Headless counterpart of the reference's main() (src/main.cc:210-239): build the default
-// scene with the reference's own construction calls, trace it on the GPU, write the frame
-// to a file and print the elapsed time.
-//   rt_main [--width W] [--height H] [--depth D] [--device N] [--out frame.bmp|frame.ppm]
+// Headless counterpart of the reference's main() (src/main.cc:210-239): build a scene with
+// the reference's own construction calls, trace it on the GPU, write the frame to a file
+// and print the elapsed time.
+//   rt_main [--scene default|spheres1024|glass] [--orbit DEGREES] [--width W] [--height H]
+//           [--depth D] [--device N] [--out frame.bmp|frame.ppm]
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 
+#include "scene_builders.hpp"
 #include "scene_model.hpp"
-
-// Same objects, lights and literals as the reference's SetupScene (src/main.cc:153-206):
-// a grey floor, a glassy violet sphere, an opaque orange sphere behind it, two lights.
-static void SetupScene(std::vector<std::unique_ptr<Object>>& objs, std::vector<std::unique_ptr<PointLight>>& lights,
-                       Color& bgr) {
-    const Light ambient{bgr, 0.3f};
-    const Color grey = Color{1.0, 1.0, 1.0} * 0.5;
-    const Color violet{0.5, 0.313, 0.64};
-    const Color orange{0.9, 0.4, 0.298};
-
-    objs.push_back(std::make_unique<Plane>(gmtl::Vec3d{0, -3, 0}, gmtl::Vec3d{0, 1, 0},
-                                           DiffuseMaterial{grey, grey, Color{0, 0, 0} * 0.5, 0, 0}, ambient));
-    objs.push_back(std::make_unique<Sphere>(gmtl::Vec3d{2, 0.5, 10}, 1,
-                                            DiffuseMaterial{violet, violet, violet, .7, .9f, 1.1}, ambient));
-    objs.push_back(std::make_unique<Sphere>(gmtl::Vec3d{1.5, 0, 13}, 1,
-                                            DiffuseMaterial{orange, orange, orange, 0.2f, 0.f}, ambient));
-
-    lights.push_back(std::make_unique<PointLight>(Color{1, 1, 1}, 1.f, gmtl::Vec3d{0, 4, 7}));
-    lights.push_back(std::make_unique<PointLight>(Color{1, 1, 1}, .3f, gmtl::Vec3d{10, 8, 3}));
-}
 
 int main(int argc, char** argv) {
     std::size_t width = 640, height = 640;  // src/main.cc:215
     TracerOptions opt;
     std::string out = "frame.bmp";
+    std::string scene = "default";
+    double orbit_deg = 0.0;
     for (int i = 1; i < argc; ++i) {
         auto next = [&]() -> const char* {
             if (i + 1 >= argc) { std::cerr << "missing value after " << argv[i] << "\n"; std::exit(2); }
@@ -43,7 +27,13 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--depth")) opt.max_depth = std::atoi(next());
         else if (!std::strcmp(argv[i], "--device")) opt.device = std::atoi(next());
         else if (!std::strcmp(argv[i], "--out")) out = next();
-        else { std::cerr << "usage: rt_main [--width W] [--height H] [--depth D] [--device N] [--out file]\n"; return 2; }
+        else if (!std::strcmp(argv[i], "--scene")) scene = next();
+        else if (!std::strcmp(argv[i], "--orbit")) orbit_deg = std::atof(next());
+        else {
+            std::cerr << "usage: rt_main [--scene default|spheres1024|glass] [--orbit DEGREES] [--width W] "
+                         "[--height H] [--depth D] [--device N] [--out file]\n";
+            return 2;
+        }
     }
 
     const auto t0 = std::chrono::high_resolution_clock::now();
@@ -53,7 +43,11 @@ int main(int argc, char** argv) {
     std::vector<std::unique_ptr<PointLight>> lights;
     Color bgr = Color{0.58, 0.76, 0.92};
     screen->ClearScreenColor(bgr);
-    SetupScene(objs, lights, bgr);
+    if (scene == "default") SetupScene(objs, lights, bgr);
+    else if (scene == "spheres1024") SetupRandomSpheresScene(objs, lights, bgr);
+    else if (scene == "glass") SetupGlassScene(objs, lights, bgr);
+    else { std::cerr << "unknown scene " << scene << "\n"; return 2; }
+    if (orbit_deg != 0.0) OrbitScene(objs, lights, orbit_deg * 3.141592653589793 / 180.0);
 
     try {
         Tracer(bgr, *screen, objs, lights, opt);

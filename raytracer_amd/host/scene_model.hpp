@@ -17,6 +17,7 @@
 #include <array>
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -96,6 +97,11 @@ public:
     // The record the device library takes for this collider.
     virtual rt_prim Flatten() const = 0;
 
+    // The same object after a rigid motion: positions go through move(v, pivot), directions
+    // through move(v, 0) (and are normalised again by the constructor).
+    using Motion = std::function<gmtl::Vec3d(const gmtl::Vec3d&, const gmtl::Vec3d&)>;
+    virtual std::unique_ptr<Object> Moved(const Motion& move, const gmtl::Vec3d& pivot) const = 0;
+
 protected:
     rt_prim FlattenMaterial(int32_t type) const {
         rt_prim p{};
@@ -121,6 +127,10 @@ public:
         for (unsigned i = 0; i < 3; ++i) { p.p[i] = origin_[i]; p.q[i] = normal_[i]; }
         return p;
     }
+    std::unique_ptr<Object> Moved(const Motion& move, const gmtl::Vec3d& pivot) const override {
+        return std::make_unique<Plane>(move(origin_, pivot), move(normal_, gmtl::Vec3d{0, 0, 0}), material_,
+                                       ambient_light_);
+    }
 
 private:
     gmtl::Vec3d origin_;
@@ -138,6 +148,9 @@ public:
         for (unsigned i = 0; i < 3; ++i) p.p[i] = center_[i];
         p.q[0] = radius_;
         return p;
+    }
+    std::unique_ptr<Object> Moved(const Motion& move, const gmtl::Vec3d& pivot) const override {
+        return std::make_unique<Sphere>(move(center_, pivot), static_cast<float>(radius_), material_, ambient_light_);
     }
 
 private:

@@ -36,6 +36,27 @@ def test_cpp_host_program_matches_checker(tmp_path):
     assert np.array_equal(rgb[::-1, :, ::-1], img)
 
 
+@pytest.mark.parametrize("scene,depth,orbit", [("glass", 8, 0.0), ("spheres1024", 5, 0.0), ("default", 5, 40.0)])
+def test_cpp_host_program_other_scenes(tmp_path, scene, depth, orbit):
+    """rt_main on the scenes of the larger configurations and on an orbit view (all built by
+    the C++ host's own builders) against the checker on the Python builders' scenes."""
+    import math
+
+    exe = os.path.join(ROOT, "raytracer_amd", "host", "rt_main")
+    out = str(tmp_path / "f.bmp")
+    cmd = [exe, "--scene", scene, "--width", "96", "--height", "64", "--depth", str(depth), "--out", out]
+    if orbit:
+        cmd += ["--orbit", str(orbit)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    build = {"glass": scenes.glass_scene, "spheres1024": scenes.random_spheres_scene, "default": scenes.default_scene}
+    prims, lights = build[scene]()
+    if orbit:
+        prims, lights = scenes.orbit_scene(prims, lights, orbit * 3.141592653589793 / 180.0)
+    ora = oracle_lib.render(prims, lights, abi.make_params(96, 64, depth), want_ids=False, want_masks=False)
+    assert_parity(dict(bgr=frame.read_bmp(out)), ora, f"rt_main {scene}")
+
+
 def test_render_device_on_torch_stream(tracer):
     import torch
 

@@ -99,3 +99,53 @@ def test_bmp_ppm_writers(tmp_path):
         assert data.startswith(head)
         rgb = np.frombuffer(data[len(head) :], dtype=np.uint8).reshape(h, w, 3)
         assert np.array_equal(rgb, img[::-1, :, ::-1])
+
+
+BUILDERS_SRC = r"""
+#include <cstdio>
+#include "scene_builders.hpp"
+static void dump(FILE* f, const ObjectList& objs, const LightList& lights) {
+    for (auto& o : objs) { rt_prim p = o->Flatten(); fwrite(&p, sizeof p, 1, f); }
+    for (auto& l : lights) { rt_light p = l->Flatten(); fwrite(&p, sizeof p, 1, f); }
+}
+int main(int argc, char** argv) {
+    FILE* f = fopen(argv[1], "wb");
+    Color bgr{0.58, 0.76, 0.92};
+    { ObjectList o; LightList l; SetupScene(o, l, bgr); dump(f, o, l); }
+    { ObjectList o; LightList l; SetupRandomSpheresScene(o, l, bgr); dump(f, o, l); }
+    { ObjectList o; LightList l; SetupGlassScene(o, l, bgr); dump(f, o, l); }
+    { ObjectList o; LightList l; SetupScene(o, l, bgr); OrbitScene(o, l, 0.7); dump(f, o, l); }
+    { ObjectList o; LightList l; SetupGlassScene(o, l, bgr, 5, 3, 77); OrbitScene(o, l, -2.1); dump(f, o, l); }
+    fclose(f);
+    return 0;
+}
+"""
+
+
+def test_cpp_scene_builders_match_python_builders(tmp_path):
+    """The C++ host's scenes for every benchmark configuration (default, 1024 spheres, glass,
+    camera orbit) flatten to the bytes of the Python builders: one scene definition, two hosts."""
+    host = os.path.join(ROOT, "raytracer_amd", "host")
+    src = tmp_path / "dump2.cpp"
+    src.write_text(BUILDERS_SRC)
+    exe = tmp_path / "dump2"
+    subprocess.run(
+        ["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I", host, "-o", str(exe), str(src),
+         os.path.join(host, "scene_model.cpp"), os.path.join(host, "scene_builders.cpp"),
+         "-L", os.path.join(ROOT, "raytracer_amd"), "-lrt_hip", "-Wl,-rpath," + os.path.join(ROOT, "raytracer_amd")],
+        check=True,
+    )
+    blob = tmp_path / "scenes.bin"
+    subprocess.run([str(exe), str(blob)], check=True)
+    raw = blob.read_bytes()
+    d = scenes.default_scene()
+    g5 = scenes.glass_scene(5, 3, 77)
+    want = [d, scenes.random_spheres_scene(), scenes.glass_scene(), scenes.orbit_scene(*d, 0.7),
+            scenes.orbit_scene(*g5, -2.1)]
+    off = 0
+    for k, (pr, lt) in enumerate(want):
+        n = pr.nbytes + lt.nbytes
+        assert raw[off : off + pr.nbytes] == pr.tobytes(), f"scene {k}: objects differ"
+        assert raw[off + pr.nbytes : off + n] == lt.tobytes(), f"scene {k}: lights differ"
+        off += n
+    assert off == len(raw)
