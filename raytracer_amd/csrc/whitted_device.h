@@ -15,7 +15,7 @@ namespace rt {
 // Geometry of one collider + the one material value a shadow feeler needs.
 // r2 < 0 marks a plane (q = unit normal as stored by the Plane constructor);
 // otherwise a sphere with r2 = radius*radius (std::pow(radius_,2), src/objects.h:125) and
-// q = {1/radius, radius, 0} (not read by the kernels).
+// q = {radius, 0, 0} (not read by the kernels).
 struct DGeom {
     double p[3];
     double q[3];

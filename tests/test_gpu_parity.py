@@ -205,6 +205,38 @@ def test_sphere_tree_ties_and_first_occluder(tracer):
     assert lin["counters"] == dev["counters"] and np.array_equal(lin["hit_mask"], dev["hit_mask"])
 
 
+def _scaled(prims, lights, k):
+    pr, lt = prims.copy(), lights.copy()
+    pr["p"] = pr["p"] * k
+    sph = pr["type"] == abi.RT_PRIM_SPHERE
+    q = pr["q"].copy()
+    q[sph, 0] = np.float32(q[sph, 0] * k).astype(np.float64)  # radii are floats in the reference
+    pr["q"] = q
+    lt["pos"] = lt["pos"] * k
+    return pr, lt
+
+
+@pytest.mark.parametrize("k", [1e-3, 37.0, 1e4, 1e7])
+@pytest.mark.parametrize("name", ["default", "spheres96"])
+def test_scene_scales(tracer, name, k):
+    """The same scenes at other length scales (millimetres to 10^7 units): the float
+    filters' error bounds scale with the coordinates, the 1e-4 ray offset does not, so
+    grazing and self-intersection cases change character; results must stay the checker's."""
+    prims, lights = scenes.default_scene() if name == "default" else scenes.random_spheres_scene(96, 3, seed=0x5CA1E)
+    prims, lights = _scaled(prims, lights, k)
+    p = abi.make_params(112, 80, 5)
+    dev, ora = _both(tracer, prims, lights, p)
+    assert_parity(dev, ora, f"{name} x{k}")
+
+
+def test_many_spheres_and_lights(tracer):
+    """4000 spheres, 12 lights: tree depth 12, 48 k (light, object) pairs."""
+    prims, lights = scenes.random_spheres_scene(4000, 12, seed=0xB16)
+    p = abi.make_params(56, 32, 4)
+    dev, ora = _both(tracer, prims, lights, p)
+    assert_parity(dev, ora, "4000 spheres")
+
+
 @pytest.mark.parametrize("band_rows,step", [(1, 2), (8, 2), (8, 8), (16, 3), (5, 4)])
 def test_strips_reassemble(tracer, band_rows, step):
     """Rendering the frame as `step` interleaved strips gives the same bytes as the
