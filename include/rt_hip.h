@@ -204,6 +204,20 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
 int rt_debug_intersect(rt_ctx* ctx, const double* rays, int32_t n, int32_t prim,
                        double* t_out, uint8_t* hit_out, double* unit_out);
 
+/*
+ * Test hook: the shadow-feeler search of Object::Shade (src/objects.h:31-47) on its own,
+ * run exactly as the render kernel runs it (its float filters first, then the double
+ * tests), for n caller-supplied surface points.
+ *   points      n * 3 doubles on the host
+ *   light       index of the light the feelers aim at
+ *   self        index of the object that is skipped (the shaded one), -1 = none
+ *   flags       RT_FLAG_LINEAR / RT_FLAG_TREE as in rt_params.flags, 0 = by scene size
+ *   first_out   n int32: index of the first occluder in container order, -1 = none
+ *   factor_out  n doubles: its transmission factor (src/objects.h:40-46), 1.0 when none
+ */
+int rt_debug_occluder(rt_ctx* ctx, const double* points, int32_t n, int32_t light, int32_t self,
+                      uint32_t flags, int32_t* first_out, double* factor_out);
+
 #ifdef __cplusplus
 }
 #endif

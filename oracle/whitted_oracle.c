@@ -316,6 +316,40 @@ int oracle_render(const rt_prim* prims, int32_t n_prims, const rt_light* lights,
     return RT_OK;
 }
 
+/* The occluder search of Object::Shade (src/objects.h:31-47) on its own, for the device
+ * test hook rt_debug_occluder: for each of n points, the index of the first object in
+ * container order (other than `self`, -1 = none is skipped) that the feeler towards
+ * lights[light] collides with, or -1, and the occlusion factor (1.0 when unoccluded). */
+int oracle_occluder(const rt_prim* prims, int32_t n_prims, const rt_light* lights, int32_t n_lights,
+                    int32_t light, int32_t self, const double* points, int32_t n, int32_t* first_out,
+                    double* factor_out) {
+    if (!prims || !lights || light < 0 || light >= n_lights || self < -1 || self >= n_prims || !points || n < 0 ||
+        !first_out || !factor_out)
+        return RT_ERR_ARG;
+    octx c;
+    memset(&c, 0, sizeof c);
+    v3 lpos = v3_make(lights[light].pos[0], lights[light].pos[1], lights[light].pos[2]);
+    for (int i = 0; i < n; ++i) {
+        v3 ip = v3_make(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
+        first_out[i] = -1;
+        factor_out[i] = 1.0;
+        for (int oi = 0; oi < n_prims; ++oi) {
+            if (oi == self) continue;
+            v3 fdir = v3_unit(v3_sub(lpos, ip));
+            double p;
+            if (test_collision(&c, &prims[oi], ip, fdir, &p)) {
+                v3 no = calc_normal(&prims[oi], v3_add(ip, v3_scale(fdir, p)));
+                double facing = -v3_dot(no, fdir);
+                double fres = mix_f(pow(1 - facing, 1), 0, (double)0.1f);
+                first_out[i] = oi;
+                factor_out[i] = (1 - fres) * prims[oi].transparency;
+                break;
+            }
+        }
+    }
+    return RT_OK;
+}
+
 /* Known-answer helpers for the device test hook (rt_debug_intersect): the collision
  * test of prims[prim] and gmtl's normalize on n caller-supplied rays (6 doubles each). */
 int oracle_intersect(const rt_prim* prims, int32_t n_prims, const double* rays, int32_t n,

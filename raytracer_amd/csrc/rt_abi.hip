@@ -495,6 +495,38 @@ int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id, ui
     return RT_OK;
 }
 
+int rt_debug_occluder(rt_ctx* ctx, const double* points, int32_t n, int32_t light, int32_t self, uint32_t flags,
+                      int32_t* first_out, double* factor_out) {
+    if (!ctx) return RT_ERR_ARG;
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    if (!points || n < 0 || !first_out || !factor_out || light < 0 || light >= ctx->n_lights || self < -1 ||
+        self >= ctx->n_prims)
+        return fail(ctx, RT_ERR_ARG, "rt_debug_occluder: bad argument");
+    if (n == 0) return RT_OK;
+    rt_params p;
+    std::memset(&p, 0, sizeof p);
+    p.width = p.height = 8; p.max_depth = 2; p.band_rows = 8; p.band_step = 1; p.band_count = 1;
+    p.fov_deg = 60.0;
+    p.flags = flags & (RT_FLAG_LINEAR | RT_FLAG_TREE);
+    rt::KArgs a;
+    int rc = make_args(ctx, &p, a);
+    if (rc != RT_OK) return rc;
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t N = static_cast<size_t>(n);
+    if ((rc = reserve(ctx, ctx->dbg_in, N * 24)) != RT_OK) return rc;
+    if ((rc = reserve(ctx, ctx->dbg_t, N * 8)) != RT_OK) return rc;
+    if ((rc = reserve(ctx, ctx->dbg_unit, N * 4)) != RT_OK) return rc;
+    RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->dbg_in.ptr, points, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP_TRY(ctx, rt::launch_debug_occluder(a, use_tree(ctx, &p), light, self,
+                                              static_cast<const double*>(ctx->dbg_in.ptr), n,
+                                              static_cast<int32_t*>(ctx->dbg_unit.ptr),
+                                              static_cast<double*>(ctx->dbg_t.ptr), ctx->stream));
+    RT_HIP_TRY(ctx, hipMemcpyAsync(first_out, ctx->dbg_unit.ptr, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP_TRY(ctx, hipMemcpyAsync(factor_out, ctx->dbg_t.ptr, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
 int rt_debug_intersect(rt_ctx* ctx, const double* rays, int32_t n, int32_t prim, double* t_out, uint8_t* hit_out,
                        double* unit_out) {
     if (!ctx) return RT_ERR_ARG;

@@ -127,6 +127,10 @@ hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, hipStream_t s
 hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, hipStream_t stream);
 
 
+// Enqueue the feeler-search hook (rt_debug_occluder); only the scene fields of `a` are read.
+hipError_t launch_debug_occluder(const KArgs& a, bool tree, int light, int self, const double* points, int n,
+                                 int32_t* first_out, double* factor_out, hipStream_t stream);
+
 // Enqueue the collision-test hook (rt_debug_intersect).
 hipError_t launch_debug_intersect(const DGeom* geom, const FGeom* fgeom, float scene_p1max, int prim, const double* rays, int n,
                                   double* t_out, uint8_t* hit_out, double* unit_out,

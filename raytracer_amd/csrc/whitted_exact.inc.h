@@ -569,6 +569,60 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
     return s;
 }
 
+// One shadow feeler (src/objects.h:31-47): the index of the first occluder in container
+// order between `ip` and light `li` (never `cur`, the shaded object), or -1; `occl`
+// receives its transmission factor.  `ffr` must hold filter_origin(ip).
+template <bool COUNT, bool TREE>
+__device__ __forceinline__ int shadow_feeler(const KArgs& a, cdata_t geom, cfdata_t fgeom, cfdata_t ltab, int li,
+                                             FilterRay& ffr, V3 ip, V3 fdir, int cur, bool cur_plane, double& occl,
+                                             uint32_t& c_sph, uint32_t& c_pln) {
+    int first = -1;  // index of the first occluder in container order
+    set_dir(ffr, fdir);
+    if (TREE) {
+        // the walk meets occluders in any order: it only keeps the one with the
+        // smallest index, whose factor is worked out afterwards
+        double pa = 0.0, pb = 0.0;  // see collides()
+        const int best = find_occluder_tree(a, geom, ffr, ip, fdir, cur, pa, pb);
+        first = (best != 0x7fffffff) ? best : -1;
+        if (first >= 0) occl = occluder_factor(a.geom + first, ip, fdir, pa, pb);
+        if (COUNT) {
+            // the tests the reference makes: objects 0..first (all when open), never `cur`
+            const bool cur_pl = cur_plane;
+            const int last = (first >= 0) ? first + 1 : a.n_prims;
+            const int tested = last - ((cur < last) ? 1 : 0);
+            const int planes = a.planes_before[last] - ((cur_pl && cur < last) ? 1 : 0);
+            c_pln += (uint32_t)planes;
+            c_sph += (uint32_t)(tested - planes);
+        }
+    } else {
+        cfdata_t lp = ltab + (size_t)li * a.ltab_stride * 4;
+        cfdata_t fp = fgeom;
+        cdata_t gp = geom;
+        int base = 0;
+        for (; base + kGroup <= a.n_prims; base += kGroup, lp += 4 * kGroup, fp += 8 * kGroup, gp += 8 * kGroup) {
+            if (!__any(first < 0)) break;
+            LRec lr[kGroup];
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) lr[j] = load_lrec(lp + 4 * j);
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j)
+                feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, true, ffr, ip, fdir, cur, first, occl, c_sph,
+                                   c_pln);
+        }
+        if (base < a.n_prims && __any(first < 0)) {
+            const int rem = a.n_prims - base;
+            LRec lr[kGroup];
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) lr[j] = load_lrec(lp + 4 * j);  // padded to whole groups
+#pragma unroll
+            for (int j = 0; j < kGroup - 1; ++j)
+                feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, j < rem, ffr, ip, fdir, cur, first, occl,
+                                   c_sph, c_pln);
+        }
+    }
+    return first;
+}
+
 // The whole walk of one pixel: lane-private except for the scalar scene loads.
 // (x, k) = column and strip row; `have` is false for lanes without a pixel.
 // MW = mask words kept per lane (0: neither hit_id nor masks are produced).
@@ -676,50 +730,8 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                 const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);  // feeler.dir
                 double occl = 1.0;
                 if (COUNT) ++c_feel;
-                int first = -1;  // index of the first occluder in container order
-                set_dir(ffr, fdir);
-                if (TREE) {
-                    // the walk meets occluders in any order: it only keeps the one with the
-                    // smallest index, whose factor is worked out afterwards
-                    double pa = 0.0, pb = 0.0;  // see collides()
-                    const int best = find_occluder_tree(a, geom, ffr, ip, fdir, cur, pa, pb);
-                    first = (best != 0x7fffffff) ? best : -1;
-                    if (first >= 0) occl = occluder_factor(a.geom + first, ip, fdir, pa, pb);
-                    if (COUNT) {
-                        // the tests the reference makes: objects 0..first (all when open), never `cur`
-                        const bool cur_pl = __double2hiint(gr2) < 0;
-                        const int last = (first >= 0) ? first + 1 : a.n_prims;
-                        const int tested = last - ((cur < last) ? 1 : 0);
-                        const int planes = a.planes_before[last] - ((cur_pl && cur < last) ? 1 : 0);
-                        c_pln += (uint32_t)planes;
-                        c_sph += (uint32_t)(tested - planes);
-                    }
-                } else {
-                    cfdata_t lp = ltab + (size_t)li * a.ltab_stride * 4;
-                    cfdata_t fp = fgeom;
-                    cdata_t gp = geom;
-                    int base = 0;
-                    for (; base + kGroup <= a.n_prims; base += kGroup, lp += 4 * kGroup, fp += 8 * kGroup, gp += 8 * kGroup) {
-                        if (!__any(first < 0)) break;
-                        LRec lr[kGroup];
-#pragma unroll
-                        for (int j = 0; j < kGroup; ++j) lr[j] = load_lrec(lp + 4 * j);
-#pragma unroll
-                        for (int j = 0; j < kGroup; ++j)
-                            feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, true, ffr, ip, fdir, cur, first, occl, c_sph,
-                                               c_pln);
-                    }
-                    if (base < a.n_prims && __any(first < 0)) {
-                        const int rem = a.n_prims - base;
-                        LRec lr[kGroup];
-#pragma unroll
-                        for (int j = 0; j < kGroup; ++j) lr[j] = load_lrec(lp + 4 * j);  // padded to whole groups
-#pragma unroll
-                        for (int j = 0; j < kGroup - 1; ++j)
-                            feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, j < rem, ffr, ip, fdir, cur, first, occl,
-                                               c_sph, c_pln);
-                    }
-                }
+                const int first = shadow_feeler<COUNT, TREE>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur,
+                                                             __double2hiint(gr2) < 0, occl, c_sph, c_pln);
                 if (COUNT && first >= 0) ++c_occ;
                 // src/objects.h:50-60 (light_dir is the same vector as feeler.dir).  The
                 // reference divides by length(normal) * length(light_dir): both are 1 to a

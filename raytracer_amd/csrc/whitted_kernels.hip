@@ -157,6 +157,39 @@ __global__ void debug_intersect_kernel(const DGeom* geom_, const FGeom* fgeom_, 
     }
 }
 
+// rt_debug_occluder: one lane per point, the feeler search exactly as the render kernel runs it.
+template <bool TREE>
+__global__ void debug_occluder_kernel(KArgs a, int light, int self, const double* points, int n, int32_t* first_out,
+                                      double* factor_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const cdata_t geom = (cdata_t)(const double*)a.geom;
+    const cdata_t lights = (cdata_t)(const double*)a.lights;
+    const V3 ip = mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
+    const DLight L = load_light(lights, light);
+    const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);
+    FilterRay ffr = filter_origin(ip, a.scene_p1max);
+    double occl = 1.0;
+    uint32_t c0 = 0, c1 = 0;
+    const int first = shadow_feeler<false, TREE>(a, geom, (cfdata_t)(const float*)a.fgeom, (cfdata_t)(const float*)a.ltab,
+                                                 light, ffr, ip, fdir, self, false, occl, c0, c1);
+    first_out[i] = first;
+    factor_out[i] = occl;
+}
+
+hipError_t launch_debug_occluder(const KArgs& a, bool tree, int light, int self, const double* points, int n,
+                                 int32_t* first_out, double* factor_out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((n + 255) / 256), block(256);
+    if (tree)
+        hipLaunchKernelGGL(debug_occluder_kernel<true>, grid, block, 0, stream, a, light, self, points, n, first_out,
+                           factor_out);
+    else
+        hipLaunchKernelGGL(debug_occluder_kernel<false>, grid, block, 0, stream, a, light, self, points, n, first_out,
+                           factor_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_debug_intersect(const DGeom* geom, const FGeom* fgeom, float scene_p1max, int prim,
                                   const double* rays, int n, double* t_out, uint8_t* hit_out, double* unit_out,
                                   hipStream_t stream) {

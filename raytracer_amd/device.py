@@ -29,6 +29,7 @@ EXPORTS = (
     "rt_render_device",
     "rt_render_device_batch",
     "rt_debug_intersect",
+    "rt_debug_occluder",
 )
 
 _lib = None
@@ -62,6 +63,8 @@ def load_library():
     L.rt_render.restype, L.rt_render.argtypes = ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp]
     L.rt_render_device.restype, L.rt_render_device.argtypes = ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]
     L.rt_render_device_batch.restype, L.rt_render_device_batch.argtypes = ctypes.c_int, [vp, vp, i32, vp, vp]
+    L.rt_debug_occluder.restype = ctypes.c_int
+    L.rt_debug_occluder.argtypes = [vp, vp, i32, i32, i32, ctypes.c_uint32, vp, vp]
     L.rt_debug_intersect.restype, L.rt_debug_intersect.argtypes = ctypes.c_int, [vp, vp, i32, i32, vp, vp, vp]
     _lib = L
     return L
@@ -148,6 +151,14 @@ class DeviceTracer:
         unit = np.zeros((n, 3), dtype=np.float64)
         self._check(self._L.rt_debug_intersect(self._h, _ptr(rays), n, prim, _ptr(t), _ptr(hit), _ptr(unit)))
         return t, hit, unit
+
+    def debug_occluder(self, points: np.ndarray, light: int, self_index: int = -1, flags: int = 0):
+        points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        n = len(points)
+        first = np.zeros(n, dtype=np.int32)
+        factor = np.zeros(n, dtype=np.float64)
+        self._check(self._L.rt_debug_occluder(self._h, _ptr(points), n, light, self_index, flags, _ptr(first), _ptr(factor)))
+        return first, factor
 
 
 class BatchPlan:

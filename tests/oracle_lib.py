@@ -40,6 +40,9 @@ def lib():
         L.oracle_render.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp]
         L.oracle_intersect.restype = ctypes.c_int
         L.oracle_intersect.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]
+        L.oracle_occluder.restype = ctypes.c_int
+        L.oracle_occluder.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp,
+                                      ctypes.c_int32, vp, vp]
         L.oracle_strip_rows.restype = ctypes.c_int32
         L.oracle_strip_rows.argtypes = [vp]
         L.oracle_mask_words.restype = ctypes.c_int32
@@ -92,3 +95,19 @@ def intersect(prims, rays, prim):
     if rc != 0:
         raise ValueError(f"oracle_intersect failed: {rc}")
     return t, hit, unit
+
+
+def occluder(prims, lights, light, self_index, points):
+    """First occluder (index or -1) and occlusion factor of the feelers from `points`."""
+    L = lib()
+    prims = np.ascontiguousarray(prims, dtype=abi.PRIM_DTYPE)
+    lights = np.ascontiguousarray(lights, dtype=abi.LIGHT_DTYPE)
+    points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    n = len(points)
+    first = np.zeros(n, dtype=np.int32)
+    factor = np.zeros(n, dtype=np.float64)
+    rc = L.oracle_occluder(_ptr(prims), len(prims), _ptr(lights), len(lights), light, self_index, _ptr(points), n,
+                           _ptr(first), _ptr(factor))
+    if rc != 0:
+        raise ValueError(f"oracle_occluder failed: {rc}")
+    return first, factor

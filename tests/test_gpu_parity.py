@@ -237,6 +237,58 @@ def test_many_spheres_and_lights(tracer):
     assert_parity(dev, ora, "4000 spheres")
 
 
+def _grazing_points(prims, lights, light, rng, per_sphere=400):
+    """Surface points whose feeler towards `light` passes a sphere's silhouette within a
+    relative 1e-16 .. 1e-3 (inside and outside), from in front of, behind and far beyond it."""
+    P = np.asarray(lights[light]["pos"], dtype=np.float64)
+    pts = []
+    for pr in prims:
+        if pr["type"] != abi.RT_PRIM_SPHERE:
+            continue
+        c, r = np.asarray(pr["p"], dtype=np.float64), float(pr["q"][0])
+        w = c - P
+        dist = np.linalg.norm(w)
+        if dist <= r * 1.001:
+            continue
+        wh = w / dist
+        v = rng.normal(size=(per_sphere, 3))
+        v -= (v @ wh)[:, None] * wh
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        q = c + r * (-(r / dist) * wh + np.sqrt(1 - (r / dist) ** 2) * v)      # silhouette seen from the light
+        eps = rng.choice([-1.0, 1.0], per_sphere) * 10.0 ** rng.uniform(-16, -3, per_sphere)
+        eps[: per_sphere // 10] = 0.0
+        qe = c + (q - c) * (1 + eps)[:, None]
+        s_ = rng.choice([0.3, 0.97, 1.5, 4.0, 60.0, 3e3, 1e5], per_sphere)
+        pts.append(P + s_[:, None] * (qe - P))
+    return np.concatenate(pts)
+
+
+@pytest.mark.parametrize("name", ["default", "glass", "spheres200"])
+def test_shadow_feeler_grazing(tracer, name):
+    """The feeler search (light-anchored line test, general filter, box test of the tree,
+    double tests) on feelers that graze spheres: first occluder and transmission factor
+    equal the checker's, bit for bit, with the container-order loop and with the tree."""
+    if name == "default":
+        prims, lights = scenes.default_scene()
+    elif name == "glass":
+        prims, lights = scenes.glass_scene()
+    else:
+        prims, lights = scenes.random_spheres_scene(200, 3, seed=0x6A2E)
+    tracer.upload_scene(prims, lights)
+    rng = np.random.default_rng(99)
+    for light in range(min(len(lights), 3)):
+        pts = _grazing_points(prims, lights, light, rng, per_sphere=400 if name != "spheres200" else 40)
+        pts = np.concatenate([pts, rng.uniform(-8, 8, (2000, 3)) + np.array([0.0, 2.0, 14.0])])
+        for self_index in (-1, 0, 1):
+            f_o, k_o = oracle_lib.occluder(prims, lights, light, self_index, pts)
+            for flags in (abi.RT_FLAG_LINEAR, abi.RT_FLAG_TREE):
+                f_d, k_d = tracer.debug_occluder(pts, light, self_index, flags)
+                bad = np.nonzero(f_d != f_o)[0]
+                assert bad.size == 0, f"{name} light {light} self {self_index} flags {flags}: {bad[:5]} {f_d[bad[:5]]} {f_o[bad[:5]]}"
+                assert np.array_equal(k_d.view(np.uint64), k_o.view(np.uint64))
+        assert (f_o >= 0).any() and (f_o < 0).any()
+
+
 @pytest.mark.parametrize("band_rows,step", [(1, 2), (8, 2), (8, 8), (16, 3), (5, 4)])
 def test_strips_reassemble(tracer, band_rows, step):
     """Rendering the frame as `step` interleaved strips gives the same bytes as the
