@@ -205,6 +205,15 @@ int rt_debug_intersect(rt_ctx* ctx, const double* rays, int32_t n, int32_t prim,
                        double* t_out, uint8_t* hit_out, double* unit_out);
 
 /*
+ * Test hook: the nearest-hit loop of TraceRay (src/main.cc:37-47) on its own, run exactly
+ * as the render kernel runs it, for n caller-supplied rays (6 doubles each: origin,
+ * unit direction).  index_out: n int32, the object hit first (-1 = none); t_out: n doubles,
+ * its t (0 when none).  flags: RT_FLAG_LINEAR / RT_FLAG_TREE, 0 = by scene size.
+ */
+int rt_debug_nearest(rt_ctx* ctx, const double* rays, int32_t n, uint32_t flags,
+                     int32_t* index_out, double* t_out);
+
+/*
  * Test hook: the shadow-feeler search of Object::Shade (src/objects.h:31-47) on its own,
  * run exactly as the render kernel runs it (its float filters first, then the double
  * tests), for n caller-supplied surface points.

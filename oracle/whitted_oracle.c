@@ -350,6 +350,31 @@ int oracle_occluder(const rt_prim* prims, int32_t n_prims, const rt_light* light
     return RT_OK;
 }
 
+/* The nearest-hit loop of TraceRay (src/main.cc:37-47) on its own, for the device test hook
+ * rt_debug_nearest: per ray (6 doubles: origin, direction used as given) the index of the
+ * object hit first (-1 = none) and its t. */
+int oracle_nearest(const rt_prim* prims, int32_t n_prims, const double* rays, int32_t n, int32_t* index_out,
+                   double* t_out) {
+    if (!prims || n_prims < 1 || !rays || n < 0 || !index_out || !t_out) return RT_ERR_ARG;
+    octx c;
+    memset(&c, 0, sizeof c);
+    for (int i = 0; i < n; ++i) {
+        v3 o = v3_make(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+        v3 d = v3_make(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+        double nearest = INFINITY;
+        int cur = -1;
+        for (int oi = 0; oi < n_prims; ++oi) {
+            double t;
+            if (test_collision(&c, &prims[oi], o, d, &t)) {
+                if (t < nearest) { nearest = t; cur = oi; }
+            }
+        }
+        index_out[i] = cur;
+        t_out[i] = (cur >= 0) ? nearest : 0.0;
+    }
+    return RT_OK;
+}
+
 /* Known-answer helpers for the device test hook (rt_debug_intersect): the collision
  * test of prims[prim] and gmtl's normalize on n caller-supplied rays (6 doubles each). */
 int oracle_intersect(const rt_prim* prims, int32_t n_prims, const double* rays, int32_t n,

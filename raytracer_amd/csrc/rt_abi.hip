@@ -495,6 +495,40 @@ int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id, ui
     return RT_OK;
 }
 
+// rt_params that only carry the object-loop mode (the debug hooks read no camera fields).
+static rt_params mode_params(uint32_t flags) {
+    rt_params p;
+    std::memset(&p, 0, sizeof p);
+    p.width = p.height = 8; p.max_depth = 2; p.band_rows = 8; p.band_step = 1; p.band_count = 1;
+    p.fov_deg = 60.0;
+    p.flags = flags & (RT_FLAG_LINEAR | RT_FLAG_TREE);
+    return p;
+}
+
+int rt_debug_nearest(rt_ctx* ctx, const double* rays, int32_t n, uint32_t flags, int32_t* index_out, double* t_out) {
+    if (!ctx) return RT_ERR_ARG;
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    if (!rays || n < 0 || !index_out || !t_out) return fail(ctx, RT_ERR_ARG, "rt_debug_nearest: bad argument");
+    if (n == 0) return RT_OK;
+    const rt_params p = mode_params(flags);
+    rt::KArgs a;
+    int rc = make_args(ctx, &p, a);
+    if (rc != RT_OK) return rc;
+    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t N = static_cast<size_t>(n);
+    if ((rc = reserve(ctx, ctx->dbg_in, N * 48)) != RT_OK) return rc;
+    if ((rc = reserve(ctx, ctx->dbg_t, N * 8)) != RT_OK) return rc;
+    if ((rc = reserve(ctx, ctx->dbg_unit, N * 4)) != RT_OK) return rc;
+    RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->dbg_in.ptr, rays, N * 48, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP_TRY(ctx, rt::launch_debug_nearest(a, use_tree(ctx, &p), static_cast<const double*>(ctx->dbg_in.ptr), n,
+                                             static_cast<int32_t*>(ctx->dbg_unit.ptr),
+                                             static_cast<double*>(ctx->dbg_t.ptr), ctx->stream));
+    RT_HIP_TRY(ctx, hipMemcpyAsync(index_out, ctx->dbg_unit.ptr, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP_TRY(ctx, hipMemcpyAsync(t_out, ctx->dbg_t.ptr, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
 int rt_debug_occluder(rt_ctx* ctx, const double* points, int32_t n, int32_t light, int32_t self, uint32_t flags,
                       int32_t* first_out, double* factor_out) {
     if (!ctx) return RT_ERR_ARG;
@@ -503,11 +537,7 @@ int rt_debug_occluder(rt_ctx* ctx, const double* points, int32_t n, int32_t ligh
         self >= ctx->n_prims)
         return fail(ctx, RT_ERR_ARG, "rt_debug_occluder: bad argument");
     if (n == 0) return RT_OK;
-    rt_params p;
-    std::memset(&p, 0, sizeof p);
-    p.width = p.height = 8; p.max_depth = 2; p.band_rows = 8; p.band_step = 1; p.band_count = 1;
-    p.fov_deg = 60.0;
-    p.flags = flags & (RT_FLAG_LINEAR | RT_FLAG_TREE);
+    const rt_params p = mode_params(flags);
     rt::KArgs a;
     int rc = make_args(ctx, &p, a);
     if (rc != RT_OK) return rc;

@@ -127,6 +127,10 @@ hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, hipStream_t s
 hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, hipStream_t stream);
 
 
+// Enqueue the nearest-hit hook (rt_debug_nearest); only the scene fields of `a` are read.
+hipError_t launch_debug_nearest(const KArgs& a, bool tree, const double* rays, int n, int32_t* index_out, double* t_out,
+                                hipStream_t stream);
+
 // Enqueue the feeler-search hook (rt_debug_occluder); only the scene fields of `a` are read.
 hipError_t launch_debug_occluder(const KArgs& a, bool tree, int light, int self, const double* points, int n,
                                  int32_t* first_out, double* factor_out, hipStream_t stream);

@@ -569,6 +569,34 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
     return s;
 }
 
+// The nearest hit of a ray over all objects (src/main.cc:37-47): `cur` = its index (-1 =
+// none), `nearest` = its t.
+template <bool COUNT, bool TREE>
+__device__ __forceinline__ void find_nearest(const KArgs& a, cdata_t geom, cfdata_t fgeom, V3 o, V3 d, double& nearest,
+                                             int& cur, uint32_t& c_sph, uint32_t& c_pln) {
+    if (TREE) {
+        find_nearest_tree<COUNT>(a, geom, o, d, nearest, cur, c_sph, c_pln);
+    } else {
+        const FilterRay fr = filter_ray(o, d, a.scene_p1max);
+        cfdata_t fp = fgeom;
+        cdata_t gp = geom;
+        int base = 0;
+        for (; base + kGroup <= a.n_prims; base += kGroup, fp += 8 * kGroup, gp += 8 * kGroup) {
+            const FGroup G = load_group(fp);
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j)
+                near_slot<COUNT>(G.r[j], gp, j, base + j, true, fr, o, d, nearest, cur, c_sph, c_pln);
+        }
+        if (base < a.n_prims) {
+            const FGroup G = load_group(fp);
+            const int rem = a.n_prims - base;
+#pragma unroll
+            for (int j = 0; j < kGroup - 1; ++j)
+                near_slot<COUNT>(G.r[j], gp, j, base + j, j < rem, fr, o, d, nearest, cur, c_sph, c_pln);
+        }
+    }
+}
+
 // One shadow feeler (src/objects.h:31-47): the index of the first occluder in container
 // order between `ip` and light `li` (never `cur`, the shaded object), or -1; `occl`
 // receives its transmission factor.  `ffr` must hold filter_origin(ip).
@@ -671,27 +699,7 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
         // ---- nearest hit, src/main.cc:37-47 ----
         int cur = -1;
         double nearest = __builtin_inf();
-        if (TREE) {
-            find_nearest_tree<COUNT>(a, geom, o, d, nearest, cur, c_sph, c_pln);
-        } else {
-            const FilterRay fr = filter_ray(o, d, a.scene_p1max);
-            cfdata_t fp = fgeom;
-            cdata_t gp = geom;
-            int base = 0;
-            for (; base + kGroup <= a.n_prims; base += kGroup, fp += 8 * kGroup, gp += 8 * kGroup) {
-                const FGroup G = load_group(fp);
-#pragma unroll
-                for (int j = 0; j < kGroup; ++j)
-                    near_slot<COUNT>(G.r[j], gp, j, base + j, true, fr, o, d, nearest, cur, c_sph, c_pln);
-            }
-            if (base < a.n_prims) {
-                const FGroup G = load_group(fp);
-                const int rem = a.n_prims - base;
-#pragma unroll
-                for (int j = 0; j < kGroup - 1; ++j)
-                    near_slot<COUNT>(G.r[j], gp, j, base + j, j < rem, fr, o, d, nearest, cur, c_sph, c_pln);
-            }
-        }
+        find_nearest<COUNT, TREE>(a, geom, fgeom, o, d, nearest, cur, c_sph, c_pln);
         if (MW > 0 && level == 1) first_hit = cur;
 
         bool next_in_regs = false;

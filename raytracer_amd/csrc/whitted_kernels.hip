@@ -177,6 +177,31 @@ __global__ void debug_occluder_kernel(KArgs a, int light, int self, const double
     factor_out[i] = occl;
 }
 
+// rt_debug_nearest: one lane per ray, the nearest-hit search exactly as the render kernel runs it.
+template <bool TREE>
+__global__ void debug_nearest_kernel(KArgs a, const double* rays, int n, int32_t* index_out, double* t_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    const V3 d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    double nearest = __builtin_inf();
+    int cur = -1;
+    uint32_t c0 = 0, c1 = 0;
+    find_nearest<false, TREE>(a, (cdata_t)(const double*)a.geom, (cfdata_t)(const float*)a.fgeom, o, d, nearest, cur, c0,
+                              c1);
+    index_out[i] = cur;
+    t_out[i] = (cur >= 0) ? nearest : 0.0;
+}
+
+hipError_t launch_debug_nearest(const KArgs& a, bool tree, const double* rays, int n, int32_t* index_out, double* t_out,
+                                hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((n + 255) / 256), block(256);
+    if (tree) hipLaunchKernelGGL(debug_nearest_kernel<true>, grid, block, 0, stream, a, rays, n, index_out, t_out);
+    else hipLaunchKernelGGL(debug_nearest_kernel<false>, grid, block, 0, stream, a, rays, n, index_out, t_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_debug_occluder(const KArgs& a, bool tree, int light, int self, const double* points, int n,
                                  int32_t* first_out, double* factor_out, hipStream_t stream) {
     if (n <= 0) return hipSuccess;

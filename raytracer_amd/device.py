@@ -30,6 +30,7 @@ EXPORTS = (
     "rt_render_device_batch",
     "rt_debug_intersect",
     "rt_debug_occluder",
+    "rt_debug_nearest",
 )
 
 _lib = None
@@ -63,6 +64,8 @@ def load_library():
     L.rt_render.restype, L.rt_render.argtypes = ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp]
     L.rt_render_device.restype, L.rt_render_device.argtypes = ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]
     L.rt_render_device_batch.restype, L.rt_render_device_batch.argtypes = ctypes.c_int, [vp, vp, i32, vp, vp]
+    L.rt_debug_nearest.restype = ctypes.c_int
+    L.rt_debug_nearest.argtypes = [vp, vp, i32, ctypes.c_uint32, vp, vp]
     L.rt_debug_occluder.restype = ctypes.c_int
     L.rt_debug_occluder.argtypes = [vp, vp, i32, i32, i32, ctypes.c_uint32, vp, vp]
     L.rt_debug_intersect.restype, L.rt_debug_intersect.argtypes = ctypes.c_int, [vp, vp, i32, i32, vp, vp, vp]
@@ -151,6 +154,14 @@ class DeviceTracer:
         unit = np.zeros((n, 3), dtype=np.float64)
         self._check(self._L.rt_debug_intersect(self._h, _ptr(rays), n, prim, _ptr(t), _ptr(hit), _ptr(unit)))
         return t, hit, unit
+
+    def debug_nearest(self, rays: np.ndarray, flags: int = 0):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        n = len(rays)
+        idx = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n, dtype=np.float64)
+        self._check(self._L.rt_debug_nearest(self._h, _ptr(rays), n, flags, _ptr(idx), _ptr(t)))
+        return idx, t
 
     def debug_occluder(self, points: np.ndarray, light: int, self_index: int = -1, flags: int = 0):
         points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)

@@ -43,6 +43,8 @@ def lib():
         L.oracle_occluder.restype = ctypes.c_int
         L.oracle_occluder.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp,
                                       ctypes.c_int32, vp, vp]
+        L.oracle_nearest.restype = ctypes.c_int
+        L.oracle_nearest.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int32, vp, vp]
         L.oracle_strip_rows.restype = ctypes.c_int32
         L.oracle_strip_rows.argtypes = [vp]
         L.oracle_mask_words.restype = ctypes.c_int32
@@ -111,3 +113,17 @@ def occluder(prims, lights, light, self_index, points):
     if rc != 0:
         raise ValueError(f"oracle_occluder failed: {rc}")
     return first, factor
+
+
+def nearest(prims, rays):
+    """Index of the nearest object along each ray (-1 = none) and its t."""
+    L = lib()
+    prims = np.ascontiguousarray(prims, dtype=abi.PRIM_DTYPE)
+    rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+    n = len(rays)
+    idx = np.zeros(n, dtype=np.int32)
+    t = np.zeros(n, dtype=np.float64)
+    rc = L.oracle_nearest(_ptr(prims), len(prims), _ptr(rays), n, _ptr(idx), _ptr(t))
+    if rc != 0:
+        raise ValueError(f"oracle_nearest failed: {rc}")
+    return idx, t

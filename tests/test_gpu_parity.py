@@ -289,6 +289,65 @@ def test_shadow_feeler_grazing(tracer, name):
         assert (f_o >= 0).any() and (f_o < 0).any()
 
 
+def _grazing_rays(prims, rng, per_sphere=300):
+    """Unit rays from random origins that pass a sphere's silhouette within a relative
+    1e-16 .. 1e-3, half of them pointing away from it, plus rays grazing the planes."""
+    rays = []
+    for pr in prims:
+        if pr["type"] != abi.RT_PRIM_SPHERE:
+            continue
+        c, r = np.asarray(pr["p"], dtype=np.float64), float(pr["q"][0])
+        o = c + rng.normal(size=(per_sphere, 3)) * rng.choice([2.0, 8.0, 300.0, 2e4], (per_sphere, 1)) * max(r, 1.0)
+        w = c - o
+        dist = np.linalg.norm(w, axis=1, keepdims=True)
+        ok = (dist[:, 0] > 1.01 * r)
+        o, w, dist = o[ok], w[ok], dist[ok]
+        wh = w / dist
+        v = rng.normal(size=w.shape)
+        v -= np.sum(v * wh, axis=1, keepdims=True) * wh
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        q = c + r * (-(r / dist) * wh + np.sqrt(1 - (r / dist) ** 2) * v)
+        eps = rng.choice([-1.0, 1.0], len(o)) * 10.0 ** rng.uniform(-16, -3, len(o))
+        qe = c + (q - c) * (1 + eps)[:, None]
+        d = qe - o
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[::2] *= 1.0  # towards the sphere
+        d[1::4] *= -1.0  # a quarter away from it: only what lies behind may be hit
+        rays.append(np.concatenate([o, d], axis=1))
+    out = np.concatenate(rays)
+    # rays almost parallel to the floor plane y = -3, from just above and just below it
+    m = 2000
+    o = np.stack([rng.uniform(-20, 20, m), -3 + rng.choice([-1, 1], m) * 10.0 ** rng.uniform(-9, 0, m), rng.uniform(0, 40, m)], 1)
+    d = np.stack([rng.normal(size=m), rng.choice([-1, 1], m) * 10.0 ** rng.uniform(-8, -1, m), rng.normal(size=m)], 1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([out, np.concatenate([o, d], axis=1)])
+
+
+@pytest.mark.parametrize("name", ["default", "glass", "spheres200", "ties"])
+def test_nearest_hit_grazing(tracer, name):
+    """The nearest-hit search on rays that graze sphere silhouettes and the floor plane:
+    index and t equal the checker's bit for bit, with the container-order loop and with the
+    tree (whose box test must never drop an object the reference hits)."""
+    if name == "default":
+        prims, lights = scenes.default_scene()
+    elif name == "glass":
+        prims, lights = scenes.glass_scene()
+    elif name == "spheres200":
+        prims, lights = scenes.random_spheres_scene(200, 3, seed=0x6A2E)
+    else:  # every sphere twice: equal t at two indices
+        prims, lights = scenes.glass_scene(12, 2, seed=5)
+        prims = np.concatenate([prims, prims[1:]])
+    tracer.upload_scene(prims, lights)
+    rays = _grazing_rays(prims, np.random.default_rng(7), per_sphere=300 if name != "spheres200" else 60)
+    i_o, t_o = oracle_lib.nearest(prims, rays)
+    for flags in (abi.RT_FLAG_LINEAR, abi.RT_FLAG_TREE):
+        i_d, t_d = tracer.debug_nearest(rays, flags)
+        bad = np.nonzero(i_d != i_o)[0]
+        assert bad.size == 0, f"{name} flags {flags}: rays {bad[:5]} device {i_d[bad[:5]]} checker {i_o[bad[:5]]}"
+        assert np.array_equal(t_d.view(np.uint64), t_o.view(np.uint64))
+    assert (i_o >= 0).any() and (i_o < 0).any()
+
+
 @pytest.mark.parametrize("band_rows,step", [(1, 2), (8, 2), (8, 8), (16, 3), (5, 4)])
 def test_strips_reassemble(tracer, band_rows, step):
     """Rendering the frame as `step` interleaved strips gives the same bytes as the
