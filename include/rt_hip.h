@@ -160,6 +160,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims,
  *              depth < max_depth                                              nullable
  *   counters   filled when RT_FLAG_COUNTERS is set                            nullable
  * Replaces Tracer() + Screen::StorePixel for the rows of the partition.
+ * The copies run at the full PCIe rate when the host buffers are page-locked
+ * (hipHostMalloc / hipHostRegister), at about a third of it otherwise.
  */
 int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id,
               uint32_t* hit_mask, uint32_t* spawn_mask, rt_counters* counters);
