@@ -52,6 +52,13 @@ def load_library():
             f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
             "(or __graft_entry__.build()); there is no fallback path"
         )
+    # PyTorch's ROCm wheels carry their own copy of the HIP runtime under the system copy's
+    # SONAME; whichever is loaded first serves the whole process, and torch does not find its
+    # GPUs on top of the system copy.  So when torch is installed it goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32 = ctypes.c_void_p, ctypes.c_int32
     L.rt_mask_words.restype, L.rt_mask_words.argtypes = i32, [i32]

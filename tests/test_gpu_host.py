@@ -181,3 +181,32 @@ def test_deep_renders_on_two_streams(tracer):
         s.synchronize()
     for o in outs:
         assert np.array_equal(o.cpu().numpy(), want)
+
+
+def test_render_device_under_graph_capture(tracer):
+    """rt_render_device / rt_render_device_batch enqueue one kernel and allocate nothing (for
+    depths up to 5; deeper renders after a first call on the stream), so they can be
+    captured in a HIP graph: four frames recorded once, replayed twice."""
+    import torch
+
+    from raytracer_amd.device import BatchPlan
+
+    prims, lights = scenes.default_scene()
+    tracer.upload_scene(prims, lights)
+    dev = torch.device("cuda", 0)
+    ps = [abi.make_params(256, 160, d) for d in (2, 3, 4, 5)]
+    outs = [torch.zeros((160, 256, 3), dtype=torch.uint8, device=dev) for _ in ps]
+    plan = BatchPlan([tracer] * 2, ps[2:], [o.data_ptr() for o in outs[2:]])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        st = torch.cuda.current_stream().cuda_stream
+        tracer.render_device(ps[0], st, outs[0].data_ptr())
+        tracer.render_device(ps[1], st, outs[1].data_ptr())
+        plan.launch(st)
+    for _ in range(2):
+        for o in outs:
+            o.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for p, o in zip(ps, outs):
+            assert np.array_equal(o.cpu().numpy(), tracer.render(p, want_ids=False, want_masks=False)["bgr"])
