@@ -2,7 +2,8 @@
 //
 // One lane per pixel, one wave per 8x8 pixel tile.  The reference's recursion
 // (TraceRay, src/main.cc:19-113) becomes a per-lane depth-first walk over the ray tree
-// with an explicit stack in LDS: a hit node adds its own shaded colour, scaled by the
+// with an explicit stack (registers, LDS, then global memory, see whitted_device.h): a hit
+// node adds its own shaded colour, scaled by the
 // product of the reflection/refraction coefficients on the path from the root, pushes
 // its refraction child and goes on with its reflection child.  The combine of
 // src/main.cc:107-112 is linear in the children's colours, so this gives the same sum
@@ -14,8 +15,12 @@
 // on the CPU, so intersection parameters, hit points, normals and child rays are the
 // same bits as in the reference, and so is every comparison made on them.
 //
-// Object loops run with a wave-uniform index: the 64-byte record is fetched with scalar
-// loads and broadcast from SGPRs, the plane/sphere branch is uniform.
+// Object loops run with a wave-uniform index: records are fetched with scalar loads and
+// broadcast from SGPRs, the plane/sphere branch is uniform.  Every collision test is
+// preceded by single-precision filters that can only answer "the reference's test certainly
+// returns nullopt" (certain_miss, line_miss_from_light, box_miss below, each with its error
+// bound); large scenes walk a tree of boxes instead of the whole list (find_nearest_tree,
+// find_occluder_tree), with the container-order semantics restored from the indices.
 #pragma once
 
 #include "whitted_device.h"
