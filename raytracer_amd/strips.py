@@ -175,7 +175,8 @@ class StripExchange:
     the exchange of batch b overlaps the render of batch b+1.
     """
 
-    def __init__(self, base, render_strips, device, group=None, band_rows: int = DEFAULT_BAND_ROWS):
+    def __init__(self, base, render_strips, device, group=None, band_rows: int = DEFAULT_BAND_ROWS,
+                 exchange_alone: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -186,6 +187,9 @@ class StripExchange:
             self.world = dist.get_world_size(group)
         else:
             self.rank, self.world = 0, 1
+        # exchange_alone: run the collective even in a group of one rank (a copy), so that
+        # the whole call sequence can be exercised on a single GPU
+        self.collective = self.world > 1 or (exchange_alone and dist.is_available() and dist.is_initialized())
         self.base = np.array(base, dtype=abi.PARAMS_DTYPE)
         self.params = rank_params(self.base, self.rank, self.world, band_rows)
         self.rows = abi.strip_rows(self.params)
@@ -194,14 +198,14 @@ class StripExchange:
         self.render_strips = render_strips
         shape = (self.world, self.max_rows, self.width, 3)
         self.send = [torch.zeros(shape, dtype=torch.uint8, device=device) for _ in range(2)]
-        self.recv = [torch.zeros(shape, dtype=torch.uint8, device=device) for _ in range(2)] if self.world > 1 else None
+        self.recv = [torch.zeros(shape, dtype=torch.uint8, device=device) for _ in range(2)] if self.collective else None
         self.outs = [[self.send[s][j, : self.rows] for j in range(self.world)] for s in range(2)]
         self.src = torch.from_numpy(frame_gather_map(self.base, self.world, band_rows)).to(device)
         self.pending = [None, None]
         self.turn = 0
         # gloo cannot exchange device tensors: stage through the host (rehearsals of the
         # multi-rank code on a box without one GPU per rank; never the measured path)
-        self.staged = self.world > 1 and dist.get_backend(group) == "gloo" and torch.device(device).type != "cpu"
+        self.staged = self.collective and dist.get_backend(group) == "gloo" and torch.device(device).type != "cpu"
 
     def _exchange_staged(self, s):
         host_send = self.send[s].cpu()
@@ -218,7 +222,7 @@ class StripExchange:
         self.render_strips(s, self.params, self.outs[s])
         if self.staged:
             self._exchange_staged(s)
-        elif self.world > 1:
+        elif self.collective:
             self.pending[s] = self.dist.all_to_all_single(self.recv[s], self.send[s], group=self.group, async_op=True)
         return s
 
@@ -230,7 +234,7 @@ class StripExchange:
     def frame(self, slot: int):
         """The assembled [height, width, 3] frame this rank owns in the batch of `slot`."""
         self.wait(slot)
-        buf = self.send[slot] if self.world == 1 else self.recv[slot]
+        buf = self.recv[slot] if self.collective else self.send[slot]
         return buf.reshape(-1, self.width, 3).index_select(0, self.src)
 
     def drain(self):

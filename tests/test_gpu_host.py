@@ -210,3 +210,50 @@ def test_render_device_under_graph_capture(tracer):
         torch.cuda.synchronize()
         for p, o in zip(ps, outs):
             assert np.array_equal(o.cpu().numpy(), tracer.render(p, want_ids=False, want_masks=False)["bgr"])
+
+
+def test_strip_exchange_over_rccl_single_rank(tracer):
+    """The multi-GPU step's call sequence on one GPU: an RCCL process group of one rank,
+    batched launch into the send buffer, all_to_all_single (async) on device tensors,
+    wait, re-assembly from the receive buffer; buffers reused over four batches."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from raytracer_amd.device import BatchPlan
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        prims, lights = scenes.default_scene()
+        tracer.upload_scene(prims, lights)
+        base = abi.make_params(640, 203, 5)
+        stream = torch.cuda.current_stream()
+        plans = {}
+
+        def render_strips(slot, params, outs):
+            if slot not in plans:
+                plans[slot] = BatchPlan([tracer], [params], [outs[0].data_ptr()])
+            plans[slot].launch(stream.cuda_stream)
+
+        x = strips.StripExchange(base, render_strips, dev, exchange_alone=True)
+        assert x.collective and not x.staged
+        slots = [x.submit() for _ in range(4)]
+        x.drain()
+        want = tracer.render(base, want_ids=False, want_masks=False)["bgr"]
+        for sl in set(slots):
+            assert np.array_equal(x.frame(sl).cpu().numpy(), want)
+        # the gather path of the single-frame mode, same group
+        def render_strip(params, out):
+            tracer.render_device(params, stream.cuda_stream, out.data_ptr())
+
+        g = strips.StripGatherer(base, render_strip, dev)
+        assert np.array_equal(g.frame(g.submit()).cpu().numpy(), want)
+    finally:
+        dist.destroy_process_group()
