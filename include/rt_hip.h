@@ -77,7 +77,7 @@ typedef struct rt_light {
 #define RT_FLAG_LINEAR 2u     /* test every object in container order, as the reference
                                  does (src/main.cc:37-47), whatever the scene size       */
 #define RT_FLAG_TREE 4u       /* walk the sphere tree even for a small scene.  Without
-                                 either flag the tree is used from 32 spheres on.  The
+                                 either flag the tree is used from 40 spheres on.  The
                                  results are identical bit for bit in both modes.        */
 
 /*

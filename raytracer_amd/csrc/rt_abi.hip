@@ -112,7 +112,7 @@ int reserve_gstack(rt_ctx* ctx, void* stream, size_t bytes, void** out) {
 }
 
 // The tree pays once a ray has more spheres to test than a walk visits nodes.
-constexpr int kTreeMinSpheres = 32;
+constexpr int kTreeMinSpheres = 40;
 bool use_tree(const rt_ctx* ctx, const rt_params* p) {
     if (p->flags & RT_FLAG_LINEAR) return false;
     if (p->flags & RT_FLAG_TREE) return ctx->n_nodes > 0;

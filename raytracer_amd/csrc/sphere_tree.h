@@ -7,6 +7,7 @@
 // the node index uniform across a wave.  The walk only decides which exact tests can be left
 // out; container-order semantics are restored from the original indices the leaves carry
 // (smallest index wins a tie in t; the smallest-index occluder is the "first" one).
+// How the tree is split only changes how much the walk can skip, never a result.
 #pragma once
 
 #include <algorithm>
@@ -62,12 +63,71 @@ inline int build(std::vector<TreeSphere>& s, int lo, int hi, std::vector<FGeom>&
             bmn[k] = std::min(bmn[k], s[i].c[k] - s[i].r);
             bmx[k] = std::max(bmx[k], s[i].c[k] + s[i].r);
         }
+    // Split: binned surface-area heuristic over the centres (16 bins per axis, cost = area
+    // of the box of each side x number of spheres in it); median of the widest axis when
+    // no bin boundary separates the centres.
     int axis = 0;
     for (int k = 1; k < 3; ++k)
         if (mx[k] - mn[k] > mx[axis] - mn[axis]) axis = k;
-    const int mid = lo + (hi - lo) / 2;
-    std::nth_element(s.begin() + lo, s.begin() + mid, s.begin() + hi,
-                     [axis](const TreeSphere& a, const TreeSphere& b) { return a.c[axis] < b.c[axis]; });
+    int mid = lo + (hi - lo) / 2;
+    bool by_median = true;
+    if (hi - lo > 2) {
+        constexpr int kBins = 16;
+        double best = INFINITY, best_pos = 0.0;
+        int best_axis = -1;
+        for (int k = 0; k < 3; ++k) {
+            const double ext = mx[k] - mn[k];
+            if (!(ext > 0.0)) continue;
+            struct Bin { double mn[3], mx[3]; int n; } bins[kBins];
+            for (Bin& b : bins) { b.n = 0; for (int j = 0; j < 3; ++j) { b.mn[j] = INFINITY; b.mx[j] = -INFINITY; } }
+            for (int i = lo; i < hi; ++i) {
+                int bi = static_cast<int>((s[i].c[k] - mn[k]) / ext * kBins);
+                bi = std::min(std::max(bi, 0), kBins - 1);
+                Bin& b = bins[bi];
+                ++b.n;
+                for (int j = 0; j < 3; ++j) {
+                    b.mn[j] = std::min(b.mn[j], s[i].c[j] - s[i].r);
+                    b.mx[j] = std::max(b.mx[j], s[i].c[j] + s[i].r);
+                }
+            }
+            const auto area = [](const double* a, const double* b) {
+                const double x = b[0] - a[0], y = b[1] - a[1], z = b[2] - a[2];
+                return x * y + y * z + z * x;
+            };
+            double rmn[kBins][3], rmx[kBins][3];
+            int rn[kBins];
+            double amn[3] = {INFINITY, INFINITY, INFINITY}, amx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int an = 0;
+            for (int b = kBins - 1; b >= 0; --b) {  // suffix boxes
+                an += bins[b].n;
+                for (int j = 0; j < 3; ++j) { amn[j] = std::min(amn[j], bins[b].mn[j]); amx[j] = std::max(amx[j], bins[b].mx[j]); }
+                rn[b] = an;
+                for (int j = 0; j < 3; ++j) { rmn[b][j] = amn[j]; rmx[b][j] = amx[j]; }
+            }
+            double lmn[3] = {INFINITY, INFINITY, INFINITY}, lmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int ln = 0;
+            for (int b = 0; b + 1 < kBins; ++b) {  // split between bin b and b + 1
+                ln += bins[b].n;
+                for (int j = 0; j < 3; ++j) { lmn[j] = std::min(lmn[j], bins[b].mn[j]); lmx[j] = std::max(lmx[j], bins[b].mx[j]); }
+                if (ln == 0 || rn[b + 1] == 0) continue;
+                const double cost = area(lmn, lmx) * ln + area(rmn[b + 1], rmx[b + 1]) * rn[b + 1];
+                if (cost < best) { best = cost; best_axis = k; best_pos = mn[k] + ext * (b + 1) / kBins; }
+            }
+        }
+        if (best_axis >= 0) {
+            const auto it = std::partition(s.begin() + lo, s.begin() + hi, [&](const TreeSphere& t) {
+                int bi = static_cast<int>((t.c[best_axis] - mn[best_axis]) / (mx[best_axis] - mn[best_axis]) * kBins);
+                bi = std::min(std::max(bi, 0), kBins - 1);
+                return mn[best_axis] + (mx[best_axis] - mn[best_axis]) * (bi + 1) / kBins <= best_pos;
+            });
+            const int m = static_cast<int>(it - s.begin());
+            // keep both sides above an eighth of the range: bounds the depth of the tree
+            if (m - lo >= (hi - lo) / 8 && hi - m >= (hi - lo) / 8 && m > lo && m < hi) { mid = m; by_median = false; }
+        }
+    }
+    if (by_median)
+        std::nth_element(s.begin() + lo, s.begin() + mid, s.begin() + hi,
+                         [axis](const TreeSphere& a, const TreeSphere& b) { return a.c[axis] < b.c[axis]; });
     // box of the member spheres around a FLOAT centre (so that the centre is exact on the
     // device), half extents measured from it and rounded up
     FGeom g;
