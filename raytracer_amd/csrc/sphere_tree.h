@@ -28,6 +28,8 @@ struct TreeSphere {
 
 namespace detail {
 
+constexpr int kLeafGroup = 4;
+
 inline float up(float v) { return std::nextafter(v, INFINITY); }
 
 inline void put_int(float& slot, int32_t v) { std::memcpy(&slot, &v, sizeof v); }
@@ -142,12 +144,20 @@ inline int build(std::vector<TreeSphere>& s, int lo, int hi, std::vector<FGeom>&
         e1 += std::fabs(static_cast<double>(cf)) + hf;
     }
     *extent1 = std::max(*extent1, e1);
-    const int min_l = build(s, lo, mid, out, extent1);
-    const int min_r = build(s, mid, hi, out, extent1);
+    int min_index;
+    if (hi - lo <= kLeafGroup) {
+        // a box directly over up to kLeafGroup spheres: cheaper than two more levels of boxes
+        min_index = s[lo].index;
+        for (int i = lo; i < hi; ++i) min_index = std::min(min_index, build(s, i, i + 1, out, extent1));
+    } else {
+        const int min_l = build(s, lo, mid, out, extent1);
+        const int min_r = build(s, mid, hi, out, extent1);
+        min_index = std::min(min_l, min_r);
+    }
     put_int(g.v[6], static_cast<int32_t>(out.size()));
-    put_int(g.v[7], std::min(min_l, min_r));
+    put_int(g.v[7], min_index);
     out[self] = g;
-    return std::min(min_l, min_r);
+    return min_index;
 }
 
 }  // namespace detail

@@ -20,3 +20,6 @@ for name, (pr, lt), d in [("glass24", scenes.glass_scene(), 8)] + [(f"spheres{n}
     lin = timeit(abi.make_params(1920, 1080, d, flags=abi.RT_FLAG_LINEAR))
     tree = timeit(abi.make_params(1920, 1080, d, flags=abi.RT_FLAG_TREE))
     print(f"{name}: linear {lin:.3f} ms  tree {tree:.3f} ms  ratio {lin/tree:.2f}", flush=True)
+pr, lt = scenes.random_spheres_scene()
+t.upload_scene(pr, lt)
+print(f"spheres1024 4K D5: linear {timeit(abi.make_params(3840, 2160, 5, flags=abi.RT_FLAG_LINEAR), 2):.1f} ms  tree {timeit(abi.make_params(3840, 2160, 5), 3):.1f} ms ratio", flush=True)
