@@ -378,7 +378,10 @@ def main():
                 "frac": achieved / PEAK_FP64_VALU_TFLOPS,
                 "frac_of_fp32_packed_peak": achieved / PEAK_FP32_PACKED_VALU_TFLOPS,
                 "traffic": _traffic_bytes(args.workload) if world == 1 else None,
-                "kernel": "whitted_batch_kernel" if mode == "strips" else "whitted_kernel<0,false>",
+                # template arguments: mask words, counters, sphere tree, deep stack
+                "kernel": ("whitted_batch_kernel<%s,%s>" if mode == "strips" else "whitted_kernel<0,false,%s,%s>")
+                % (("true" if len(prims) - int((prims["type"] == abi.RT_PRIM_PLANE).sum()) >= 40 else "false"),
+                   ("true" if depth > 5 else "false")),
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": my_flops,
                 "framebuffer_write_GBps": fb_bytes / (kernel_ms * 1e-3) / 1e9,
