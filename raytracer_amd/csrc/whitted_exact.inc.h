@@ -538,18 +538,22 @@ __device__ __forceinline__ void near_slot(const FRec& gf, cdata_t gp, int j, int
 // Slot of a shadow feeler's loop (src/objects.h:31-47): the first occluder in container
 // order decides, the shaded object itself is skipped.  `first` = its index (-1 while none),
 // `factor` = its transmission factor.
-template <bool COUNT>
+template <bool COUNT, bool LATE>
 __device__ __forceinline__ void feeler_slot(const LRec& lr, cfdata_t fp, cdata_t gp, int j, int idx, bool valid,
                                             const FilterRay& fr, V3 ip, V3 fdir, int cur, int& first, double& factor,
                                             uint32_t& c_sph, uint32_t& c_pln) {
+    // Whether the reference makes this test at all (no occluder met yet, not the shaded
+    // object) can be asked before the line test or, LATE, only by the lanes the line test
+    // leaves (for the others nothing follows from the answer).  LATE is cheaper per object
+    // but sends every lane through the branch at its own object: it pays with many lights.
     const bool tested = valid && first < 0 && idx != cur;
     if (COUNT && tested) { if (lr.thr == -__builtin_inff()) ++c_pln; else ++c_sph; }
-    if (tested && !line_miss_from_light(lr, fr)) {
+    if ((LATE ? valid : tested) && !line_miss_from_light(lr, fr)) {
         __asm__ volatile("" ::: "memory");  // the rest only for the lanes the line test leaves
         const FRec gf = load_rec(fp + 8 * j);
         const DGeom g = load_geom(gp, j);
         double p;
-        if (!certain_miss(gf, fr) && test_collision(g, ip, fdir, p)) {
+        if ((!LATE || (first < 0 && idx != cur)) && !certain_miss(gf, fr) && test_collision(g, ip, fdir, p)) {
             // src/objects.h:40-46, here with the object's record still in scalar registers
             const V3 hp = ip + fdir * p;
             const V3 no = unit((__double2hiint(g.r2) < 0) ? mk(g.q[0], g.q[1], g.q[2]) : (hp - mk(g.p[0], g.p[1], g.p[2])));
@@ -605,7 +609,7 @@ __device__ __forceinline__ void find_nearest(const KArgs& a, cdata_t geom, cfdat
 // One shadow feeler (src/objects.h:31-47): the index of the first occluder in container
 // order between `ip` and light `li` (never `cur`, the shaded object), or -1; `occl`
 // receives its transmission factor.  `ffr` must hold filter_origin(ip).
-template <bool COUNT, bool TREE>
+template <bool COUNT, bool TREE, bool LATE>
 __device__ __forceinline__ int shadow_feeler(const KArgs& a, cdata_t geom, cfdata_t fgeom, cfdata_t ltab, int li,
                                              FilterRay& ffr, V3 ip, V3 fdir, int cur, bool cur_plane, double& occl,
                                              uint32_t& c_sph, uint32_t& c_pln) {
@@ -639,7 +643,7 @@ __device__ __forceinline__ int shadow_feeler(const KArgs& a, cdata_t geom, cfdat
             for (int j = 0; j < kGroup; ++j) lr[j] = load_lrec(lp + 4 * j);
 #pragma unroll
             for (int j = 0; j < kGroup; ++j)
-                feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, true, ffr, ip, fdir, cur, first, occl, c_sph,
+                feeler_slot<COUNT, LATE>(lr[j], fp, gp, j, base + j, true, ffr, ip, fdir, cur, first, occl, c_sph,
                                    c_pln);
         }
         if (base < a.n_prims && __any(first < 0)) {
@@ -649,7 +653,7 @@ __device__ __forceinline__ int shadow_feeler(const KArgs& a, cdata_t geom, cfdat
             for (int j = 0; j < kGroup; ++j) lr[j] = load_lrec(lp + 4 * j);  // padded to whole groups
 #pragma unroll
             for (int j = 0; j < kGroup - 1; ++j)
-                feeler_slot<COUNT>(lr[j], fp, gp, j, base + j, j < rem, ffr, ip, fdir, cur, first, occl,
+                feeler_slot<COUNT, LATE>(lr[j], fp, gp, j, base + j, j < rem, ffr, ip, fdir, cur, first, occl,
                                    c_sph, c_pln);
         }
     }
@@ -662,7 +666,8 @@ __device__ __forceinline__ int shadow_feeler(const KArgs& a, cdata_t geom, cfdat
 // TREE = walk the sphere tree instead of the whole object list (large scenes).
 // DEEP = the stack may reach its global-memory part (max_depth > 3 + kStackLdsEntries);
 //        without it that code is left out, which the register allocation needs.
-template <int MW, bool COUNT, bool TREE, bool DEEP>
+// LATE = see feeler_slot() (container-order shadow loops of scenes with many lights).
+template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE = false>
 __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const int k, bool have, double* stk,
                                             double* gstk, const int lane, uint32_t (&cnt)[8]) {
     const cdata_t geom = (cdata_t)(const double*)a.geom;
@@ -743,7 +748,7 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                 const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);  // feeler.dir
                 double occl = 1.0;
                 if (COUNT) ++c_feel;
-                const int first = shadow_feeler<COUNT, TREE>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur,
+                const int first = shadow_feeler<COUNT, TREE, LATE>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur,
                                                              __double2hiint(gr2) < 0, occl, c_sph, c_pln);
                 if (COUNT && first >= 0) ++c_occ;
                 // src/objects.h:50-60 (light_dir is the same vector as feeler.dir).  The

@@ -8,6 +8,11 @@ namespace rt {
 
 using namespace exact;
 
+// From this many lights on the container-order shadow loops use the late predicate
+// (feeler_slot's LATE): measured on the default scene (2 lights, 2 % slower with it) and
+// the glass scene (16 lights, 13 % faster).
+constexpr int kLateMinLights = 4;
+
 template <bool COUNT>
 __device__ __forceinline__ void flush_counters(const KArgs& a, const uint32_t (&cnt)[8], int lane) {
     if (COUNT) {
@@ -30,7 +35,7 @@ __device__ __forceinline__ double* wave_gstack(const KArgs& a, int tx, int ty) {
 }
 
 // One wave per 8x8 pixel tile of the strip.
-template <int MW, bool COUNT, bool TREE, bool DEEP>
+template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? 4 : 3, 4))) void whitted_kernel(KArgs a) {
     extern __shared__ double lds_stack[];
     const int lane = threadIdx.x & 63;
@@ -43,16 +48,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     const bool have = (x < a.width) && (k < a.rows);
     double* gstk = wave_gstack(a, tx, ty);
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    trace_pixel<MW, COUNT, TREE, DEEP>(a, x, k, have, stk, gstk, lane, cnt);
+    trace_pixel<MW, COUNT, TREE, DEEP, LATE>(a, x, k, have, stk, gstk, lane, cnt);
     flush_counters<COUNT>(a, cnt, lane);
 }
 
-template <int MW, bool COUNT, bool TREE, bool DEEP>
-static hipError_t launch_ttd(const KArgs& a, hipStream_t stream) {
+template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
+static hipError_t launch_ttdl(const KArgs& a, hipStream_t stream) {
     const int bx = (a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     if (bx <= 0 || a.tiles_y <= 0) return hipSuccess;
     const size_t lds = stack_lds_bytes(a.max_depth);
-    hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
+    hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -60,7 +65,7 @@ static hipError_t launch_ttd(const KArgs& a, hipStream_t stream) {
 // partition and output), the arguments of all of them travel by value in the kernel
 // argument segment.  Image-only variant; the grid is sized for the largest render, blocks
 // outside a smaller one return at once.
-template <bool TREE, bool DEEP>
+template <bool TREE, bool DEEP, bool LATE>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void whitted_batch_kernel(KBatch b) {
     extern __shared__ double lds_stack[];
@@ -76,7 +81,7 @@ void whitted_batch_kernel(KBatch b) {
     const bool have = (x < a.width) && (k < a.rows);
     double* gstk = wave_gstack(a, tx, ty);
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    trace_pixel<0, false, TREE, DEEP>(a, x, k, have, stk, gstk, lane, cnt);
+    trace_pixel<0, false, TREE, DEEP, LATE>(a, x, k, have, stk, gstk, lane, cnt);
 }
 
 hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, hipStream_t stream) {
@@ -91,11 +96,23 @@ hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, hipStream_t s
     const dim3 grid(bx, by, n), block(64 * kWavesPerBlock);
     const size_t lds = stack_lds_bytes(depth);
     const bool deep = stack_global_entries(depth) > 0;
-    if (tree && deep) hipLaunchKernelGGL((whitted_batch_kernel<true, true>), grid, block, lds, stream, b);
-    else if (tree) hipLaunchKernelGGL((whitted_batch_kernel<true, false>), grid, block, lds, stream, b);
-    else if (deep) hipLaunchKernelGGL((whitted_batch_kernel<false, true>), grid, block, lds, stream, b);
-    else hipLaunchKernelGGL((whitted_batch_kernel<false, false>), grid, block, lds, stream, b);
+    bool late = !tree;  // every render of the batch must have many lights
+    for (int i = 0; i < n; ++i) late = late && b.a[i].n_lights >= kLateMinLights;
+    if (tree && deep) hipLaunchKernelGGL((whitted_batch_kernel<true, true, false>), grid, block, lds, stream, b);
+    else if (tree) hipLaunchKernelGGL((whitted_batch_kernel<true, false, false>), grid, block, lds, stream, b);
+    else if (deep && late) hipLaunchKernelGGL((whitted_batch_kernel<false, true, true>), grid, block, lds, stream, b);
+    else if (deep) hipLaunchKernelGGL((whitted_batch_kernel<false, true, false>), grid, block, lds, stream, b);
+    else if (late) hipLaunchKernelGGL((whitted_batch_kernel<false, false, true>), grid, block, lds, stream, b);
+    else hipLaunchKernelGGL((whitted_batch_kernel<false, false, false>), grid, block, lds, stream, b);
     return hipGetLastError();
+}
+
+// The late-predicate shadow loop exists for the image-only kernel without the tree only.
+template <int MW, bool COUNT, bool TREE, bool DEEP>
+static hipError_t launch_ttd(const KArgs& a, hipStream_t stream) {
+    if (MW == 0 && !COUNT && !TREE && a.n_lights >= kLateMinLights)
+        return launch_ttdl<MW, COUNT, TREE, DEEP, (MW == 0 && !COUNT && !TREE)>(a, stream);
+    return launch_ttdl<MW, COUNT, TREE, DEEP, false>(a, stream);
 }
 
 // Only the image-only kernel exists without the deep-stack code; the others always carry it.
@@ -171,7 +188,7 @@ __global__ void debug_occluder_kernel(KArgs a, int light, int self, const double
     FilterRay ffr = filter_origin(ip, a.scene_p1max);
     double occl = 1.0;
     uint32_t c0 = 0, c1 = 0;
-    const int first = shadow_feeler<false, TREE>(a, geom, (cfdata_t)(const float*)a.fgeom, (cfdata_t)(const float*)a.ltab,
+    const int first = shadow_feeler<false, TREE, false>(a, geom, (cfdata_t)(const float*)a.fgeom, (cfdata_t)(const float*)a.ltab,
                                                  light, ffr, ip, fdir, self, false, occl, c0, c1);
     first_out[i] = first;
     factor_out[i] = occl;

@@ -13,6 +13,14 @@ pytestmark = pytest.mark.gpu
 def _both(tracer, prims, lights, params, counters=True):
     tracer.upload_scene(prims, lights)
     dev = tracer.render(params, want_counters=counters)
+    if counters:
+        # the counting kernels are separate instantiations: the plain ones (with and without
+        # the id/mask outputs) must give the same frame
+        plain = tracer.render(params)
+        image_only = tracer.render(params, want_ids=False, want_masks=False)
+        for k in ("bgr", "hit_id", "hit_mask", "spawn_mask"):
+            assert np.array_equal(plain[k], dev[k]), f"counting and plain kernels differ in {k}"
+        assert np.array_equal(image_only["bgr"], dev["bgr"]), "image-only kernel differs"
     ora = oracle_lib.render(prims, lights, params, want_counters=counters)
     return dev, ora
 
