@@ -475,10 +475,12 @@ __device__ __forceinline__ void find_nearest_tree(const KArgs& a, cdata_t geom, 
 // and prunes every node that only holds larger indices.  Returns the index or INT_MAX.
 __device__ __forceinline__ void feeler_candidate(const FRec& gf, cdata_t geom, int idx, const FilterRay& fr, V3 ip, V3 fdir,
                                                  int cur, int& best, double& pa, double& pb) {
-    if (idx != cur && idx < best && !certain_miss(gf, fr)) {
+    if (!certain_miss(gf, fr)) {
         __asm__ volatile("" ::: "memory");
-        const DGeom g = load_geom(geom, idx);
-        if (collides(g, ip, fdir, pa, pb)) best = idx;
+        if (idx != cur && idx < best) {  // asked only of the lanes the filter leaves
+            const DGeom g = load_geom(geom, idx);
+            if (collides(g, ip, fdir, pa, pb)) best = idx;
+        }
     }
 }
 __device__ __forceinline__ int find_occluder_tree(const KArgs& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur,
