@@ -141,6 +141,8 @@ const char* rt_last_error(const rt_ctx* ctx);
 /*
  * Copy the scene to the device.  Replaces the `objs` / `lights` arguments of Tracer()
  * (src/main.cc:118-119).  1 <= n_prims <= RT_MAX_PRIMS, 0 <= n_lights <= RT_MAX_LIGHTS.
+ * Positions, normals, radii and light positions must be finite (RT_ERR_ARG otherwise; the
+ * reference checks nothing); a radius may be zero or negative, only its square is used.
  */
 int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims,
                     const rt_light* lights, int32_t n_lights);

@@ -259,9 +259,12 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         }
         // std::pow(radius_, 2) (src/objects.h:125) is radius_*radius_ correctly rounded.
         g.r2 = (s.type == RT_PRIM_PLANE) ? -1.0 : s.q[0] * s.q[0];
-        if (s.type == RT_PRIM_SPHERE) {
-            if (!(s.q[0] > 0.0)) return fail(ctx, RT_ERR_ARG, "rt_upload_scene: sphere radius must be positive");
-        }
+        // The reference takes any numbers; here positions, normals and radii must be finite
+        // (the tree builder and the float filters are not defined on NaN/inf input).  A radius
+        // may be zero or negative: the reference only ever uses its square.
+        for (int c = 0; c < 3; ++c)
+            if (!std::isfinite(s.p[c]) || !std::isfinite(s.q[c]))
+                return fail(ctx, RT_ERR_ARG, "rt_upload_scene: non-finite position, normal or radius");
         g.transparency = s.transparency;
         m.reflectivity = s.reflectivity;
         m.transparency = s.transparency;
@@ -270,6 +273,9 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         m.pad = 1.0 / s.refraction_index;  // src/main.cc:64, the same division done once
     }
     for (int i = 0; i < n_lights; ++i) {
+        for (int c = 0; c < 3; ++c)
+            if (!std::isfinite(lights[i].pos[c]))
+                return fail(ctx, RT_ERR_ARG, "rt_upload_scene: non-finite light position");
         std::memset(&lt[i], 0, sizeof lt[i]);
         for (int c = 0; c < 3; ++c) {
             lt[i].pos[c] = lights[i].pos[c];
@@ -315,7 +321,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
             std::memcpy(&g.v[6], &i, sizeof(int32_t));
             fplanes.push_back(g);
         } else {
-            tsph.push_back(rt::TreeSphere{{s.p[0], s.p[1], s.p[2]}, s.q[0], i});
+            tsph.push_back(rt::TreeSphere{{s.p[0], s.p[1], s.p[2]}, std::fabs(s.q[0]), i});
         }
     }
     // per (light, object) constants of the light-anchored line test (whitted_exact.inc.h)

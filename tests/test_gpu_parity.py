@@ -413,4 +413,29 @@ def test_errors(tracer):
     bad[0]["type"] = 7
     with pytest.raises(RtError):
         tracer.upload_scene(bad, lights)
+    for field, value in (("p", np.nan), ("q", np.inf)):
+        bad = prims.copy()
+        bad[1][field][0] = value
+        with pytest.raises(RtError):
+            tracer.upload_scene(bad, lights)
+    badl = lights.copy()
+    badl[0]["pos"][2] = -np.inf
+    with pytest.raises(RtError):
+        tracer.upload_scene(prims, badl)
+
+
+@pytest.mark.parametrize("n_spheres", [6, 60])
+def test_zero_and_negative_radii(tracer, n_spheres):
+    """The reference only ever squares a radius: a negative one behaves like its absolute
+    value, a zero one is a point that is practically never hit.  Both object-loop modes."""
+    prims, lights = scenes.random_spheres_scene(n_spheres, 3, seed=0x2E60)
+    prims = prims.copy()
+    q = prims["q"].copy()
+    q[1::3, 0] *= -4.0      # every third sphere negative (and bigger, so that it shows)
+    q[2::7, 0] = 0.0
+    prims["q"] = q
+    p = abi.make_params(120, 80, 5)
+    dev, ora = _both(tracer, prims, lights, p)
+    assert_parity(dev, ora, f"radii {n_spheres}")
+    assert int(ora["counters"]["hits"]) > int(ora["counters"]["primary_hits"]) > 0
     tracer.upload_scene(prims, lights)
