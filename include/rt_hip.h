@@ -130,6 +130,9 @@ int32_t rt_strip_rows(const rt_params* p);
 /* Library version, "major.minor".                                                       */
 const char* rt_version(void);
 
+/* A context is not thread-safe: calls on one rt_ctx must not overlap in host time (use one
+ * context per host thread; the work they enqueue may overlap on the device).             */
+
 /* Create a context on HIP device `device_id`.  Fails with RT_ERR_HIP when no gfx950
  * device (or no device at all) is usable: there is no CPU fallback.                     */
 int rt_create(int32_t device_id, rt_ctx** out);
