@@ -1,42 +1,49 @@
 #!/usr/bin/env python3
 """Benchmark of the Whitted trace path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode strips|batch] [--workload NAME]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode all|batch|gather|strips]
+                  [--workload NAME] [--no-extra] [--no-cpu-baseline] [--no-end-to-end]
 
-A step is one frame.  The default workload is the configuration the headline metric is
-quoted on: the reference's default scene at 3840x2160, recursion depth 5.
+A step is one pass of the trace path over one batch of synthetic input.  The default workload
+is the configuration the headline metric is quoted on: the reference's default scene at
+3840x2160, recursion depth 5.
 
-  N = 1       a step is one frame, the whole frame on one GPU.
-  N > 1       launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py
-              --gpus N ...`, one rank per GPU.
-              mode strips (default): a step is a batch of N frames, frame j owned by rank
-              j.  Every frame is cut into interleaved 8-row bands, every rank renders its
-              strip of each of the N frames (one batched launch, a frame's worth of pixels) and
-              ONE RCCL all-to-all moves strip (rank r, frame j) to rank j: the strip gather
-              for N frames at once with a different root per frame, so that all xGMI links
-              carry the same share.  The exchange of batch b overlaps the render of batch
-              b+1.  Work per GPU and step is fixed: weak scaling.
-              mode gather: a step is ONE frame, strips gathered to rank 0 (the latency
-              path; total work fixed: strong scaling).
-              mode batch: a step is one whole frame of a camera orbit per rank, no
-              collective (weak scaling).
+  N = 1   a step is one frame, the whole frame on one GPU, output resident in HBM.
+  N > 1   launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`,
+          one rank per GPU.  Three ways to use N GPUs are timed one after the other (K steps
+          each, own warm-up) and reported under "modes":
+          batch   a step is one whole frame of a camera orbit per rank, no collective (weak
+                  scaling; the multi-frame mode).  This is the mode `value` is taken from.
+          gather  a step is ONE frame cut into interleaved 8-row bands, every rank renders its
+                  strip and the strips are gathered to rank 0 over RCCL (the single-frame mode;
+                  total work fixed: strong scaling).  The re-assembly pass on rank 0
+                  (index_select of the gathered strips) is part of the timed step.
+          strips  a step is a batch of N frames; every rank renders its strip of each of them
+                  with one batched launch and ONE RCCL all-to-all moves strip (rank r, frame j)
+                  to rank j, which re-assembles its frame (weak scaling).
 
-Rank 0 prints ONE JSON line.  value = rays of all frames of all ranks / wall time of the
-timed steps (max over ranks), with scene and buffers resident in HBM before the clock
-starts.  Rays = TraceRay invocations that pass the depth stop, counted by the kernel's
-counter variant in an untimed launch (and equal to the CPU checker's count).
+Rank 0 prints ONE JSON line.  value = rays of all frames of all ranks / wall time of the timed
+steps (max over ranks), with scene and buffers resident in HBM before the clock starts.  Rays =
+TraceRay invocations that pass the depth stop, counted by the kernel's counter variant in an
+untimed launch (and equal to the CPU checker's count).
 
-roofline: the path is bound by the vector ALUs, not by MFMA or HBM, so `bound` is "valu".
-`peak` is the gfx950 FP64 vector peak, 78.6 TFLOP/s (256 CUs x 4 SIMDs x 16 lanes x 2 flop x
-2.4 GHz; the path computes in f64 - `dtype`); `frac_of_fp32_packed_peak` gives the same
-figure against the 157.3 TFLOP/s packed-FP32 vector peak.  achieved = algorithmic
-flops of one launch / mean kernel time measured with HIP events around every timed
-launch, on the stream the kernel runs on.  Algorithmic flops = event counts x a fixed
-cost table (see FLOP_TABLE).  `traffic` is the HBM bytes per launch taken from the PMC
-profile committed under profiles/ (null when none matches the workload).
+roofline: the path is bound by the vector ALUs, not by MFMA or HBM, so `bound` is "valu" and
+`peak` is the gfx950 FP32 vector peak, 157.3 TFLOP/s.  achieved = algorithmic flops of one
+launch / mean kernel time measured with HIP events around every timed launch, on the stream the
+kernel runs on.  Algorithmic flops = event counts x a fixed cost table (FLOP_TABLE): the
+reference's arithmetic as written, whatever the kernel does to avoid it (for the scene with the
+sphere tree this is the brute-force count the reference would execute, an equivalent rate).
+`frac_of_fp64_rate` gives the same figure against 78.6 TFLOP/s, the rate at which the chip
+issues the unfused double operations the path computes in.  `traffic` and the executed
+vector-instruction figures come from the PMC profiles committed under profiles/ (null when
+none matches the workload).
 
-cpu_baseline: the single-thread CPU checker (oracle/, a port of the reference's path)
+cpu_baseline: the single-thread CPU checker (oracle/, a C port of the reference's path)
 timed on this host on whole frames of the same workload, rank 0 at N=1 only.
+end_to_end (N=1): rt_render of the same frame into host memory (ordinary and page-locked), and
+the whole program (`rt_main`: process start, scene, render, BMP file) beside the CPU port's.
+extra (N=1): the 1024-sphere and the glass workloads, a few steps each, with their own
+roofline and sampled CPU baseline.
 """
 from __future__ import annotations
 
@@ -44,7 +51,9 @@ import argparse
 import json
 import math
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -55,8 +64,8 @@ if ROOT not in sys.path:
 
 from raytracer_amd import abi, scenes, strips  # noqa: E402
 
-PEAK_FP64_VALU_TFLOPS = 78.6
-PEAK_FP32_PACKED_VALU_TFLOPS = 157.3
+PEAK_FP32_VALU_TFLOPS = 157.3   # gfx950 vector peak (packed FP32 FMA)
+RATE_FP64_VALU_TFLOPS = 78.6    # 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 
 # Flops per event (mul/add/sub/div/sqrt = 1 each), the reference's arithmetic as written.
 FLOP_TABLE = {
@@ -77,6 +86,9 @@ WORKLOADS = {
     "glass_4k_d8": (scenes.glass_scene, 3840, 2160, 8),
     "default_8k_d5": (scenes.default_scene, 7680, 4320, 5),
 }
+EXTRA_WORKLOADS = ("spheres1024_4k_d5", "glass_4k_d8")
+LATE_MIN_LIGHTS = 4    # kLateMinLights of the kernel launcher
+TREE_MIN_SPHERES = 40  # kTreeMinSpheres
 
 
 def algorithmic_flops(counters, pixels: int) -> float:
@@ -85,6 +97,17 @@ def algorithmic_flops(counters, pixels: int) -> float:
         if k != "pixels":
             f += c * int(counters[k])
     return float(f)
+
+
+def kernel_name(prims, lights, depth: int, batched: bool) -> str:
+    """The instantiation the launcher picks, spelt as the profiler prints it."""
+    b = lambda v: "true" if v else "false"
+    tree = len(prims) - int((prims["type"] == abi.RT_PRIM_PLANE).sum()) >= TREE_MIN_SPHERES
+    deep = depth > 5
+    late = (not tree) and len(lights) >= LATE_MIN_LIGHTS
+    if batched:
+        return f"void rt::whitted_batch_kernel<{b(tree)}, {b(deep)}, {b(late)}>(rt::KBatch, int)"
+    return f"void rt::whitted_kernel<0, false, {b(tree)}, {b(deep)}, {b(late)}>(rt::KArgs)"
 
 
 def cpu_baseline(prims, lights, base, budget_s: float = 12.0):
@@ -129,6 +152,9 @@ def cpu_baseline(prims, lights, base, budget_s: float = 12.0):
         "unit": "Mrays/s",
         "cores": 1,
         "kind": "port",
+        "note": "C restatement of the reference's path (the reference itself needs Windows.h and gmtl and cannot "
+                "be built here); per ray it is faster than the reference's C++ (no virtual calls, no by-value "
+                "material copies), so the ratio is conservative",
         "sample": sample,
         "ms_per_frame": ms_frame,
         "cpu": _cpu_model(),
@@ -146,13 +172,330 @@ def _cpu_model():
     return "unknown"
 
 
-def _traffic_bytes(workload: str):
+def _profile_record(workload: str) -> dict:
+    """Per-launch PMC figures of the workload's kernel, from profiles/traffic.json."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(workload, {}) or {}
     except (OSError, ValueError):
-        return None
+        return {}
+
+
+def roofline(prims, lights, depth, batched, flops, kernel_ms_list, fb_bytes, workload, with_profile=True):
+    ms = np.asarray(kernel_ms_list, dtype=np.float64)
+    mean = float(ms.mean()) if ms.size else float("nan")
+    achieved = flops / (mean * 1e-3) / 1e12
+    prof = _profile_record(workload) if with_profile else {}
+    out = {
+        "bound": "valu",
+        "achieved": achieved,
+        "peak": PEAK_FP32_VALU_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+        "frac_of_fp64_rate": achieved / RATE_FP64_VALU_TFLOPS,
+        "traffic": prof.get("hbm_bytes_per_launch"),
+        "kernel": kernel_name(prims, lights, depth, batched),
+        "kernel_ms": mean,
+        "kernel_ms_min": float(ms.min()) if ms.size else None,
+        "kernel_ms_median": float(np.median(ms)) if ms.size else None,
+        "kernel_ms_max": float(ms.max()) if ms.size else None,
+        "algorithmic_flops_per_launch": flops,
+        "framebuffer_write_GBps": fb_bytes / (mean * 1e-3) / 1e9,
+    }
+    if prof.get("valu_insts_per_launch"):
+        # what the kernel really executed (PMC pass of the same launch, profiles/)
+        lane_ops = prof["valu_insts_per_launch"] * 64.0 * prof.get("lane_utilisation", 1.0)
+        out["executed"] = {
+            "valu_wave_insts_per_launch": prof["valu_insts_per_launch"],
+            "lane_utilisation": prof.get("lane_utilisation"),
+            "valu_busy": prof.get("valu_busy"),
+            "lane_ops_per_s": lane_ops / (mean * 1e-3),
+            "source": prof.get("source"),
+        }
+    return out
+
+
+class Timed:
+    """HIP events around every launch of the timed steps, on the stream the kernel runs on."""
+
+    def __init__(self, torch, stream, steps, warmup):
+        self.stream, self.steps, self.warmup = stream, steps, warmup
+        self.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        self.step_no = 0
+
+    def index(self):
+        i = self.step_no - self.warmup
+        return i if 0 <= i < self.steps else -1
+
+    def launch(self, fn):
+        i = self.index()
+        if i >= 0:
+            self.ev[i][0].record(self.stream)
+        fn()
+        if i >= 0:
+            self.ev[i][1].record(self.stream)
+
+    def kernel_ms(self):
+        return [a.elapsed_time(b) for a, b in self.ev]
+
+
+def run_mode(mode, ctx):
+    """Time `steps` steps of one mode.  Returns this rank's figures; collectives (barrier,
+    max of the wall time, sum of the rays) are done here so that every rank takes part."""
+    torch, dist = ctx["torch"], ctx["dist"]
+    world, rank, device, stream = ctx["world"], ctx["rank"], ctx["device"], ctx["stream"]
+    tracer, base, args = ctx["tracer"], ctx["base"], ctx["args"]
+    prims, lights = ctx["prims"], ctx["lights"]
+    width, height = int(base["width"]), int(base["height"])
+    timed = Timed(torch, stream, args.steps, args.warmup)
+    rays_done = [0]
+
+    if mode in ("single", "gather", "strips"):
+        my = base.copy() if mode == "single" else strips.rank_params(base, rank, world)
+    else:
+        my = base.copy()
+    my_rows = abi.strip_rows(my)
+
+    # untimed counter launch: rays and event counts of this rank's share of one frame
+    d_cnt = torch.zeros(8, dtype=torch.int64, device=device)
+    scratch = torch.zeros((max(my_rows, 1), width, 3), dtype=torch.uint8, device=device)
+    pc = my.copy()
+    pc["flags"] = abi.RT_FLAG_COUNTERS
+    tracer.render_device(pc, stream.cuda_stream, scratch.data_ptr(), d_counters=d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    cnt_host = d_cnt.cpu().numpy().astype(np.uint64)
+    counters = {f: int(cnt_host[i]) for i, f in enumerate(abi.COUNTER_FIELDS)}
+    my_flops = algorithmic_flops(counters, my_rows * width)  # of ONE render of this rank
+    my_rays = counters["rays"]
+    renders_per_launch = 1
+    gatherer = None
+    frames_per_step = 1
+    scaling = "weak"
+
+    if mode in ("single", "gather"):
+        scaling = "weak" if mode == "single" else "strong"
+
+        def render_strip(params, out):
+            timed.launch(lambda: tracer.render_device(params, stream.cuda_stream, out.data_ptr()))
+
+        gatherer = strips.StripGatherer(base, render_strip, device)
+
+        prev = [None]
+
+        def step():
+            slot = gatherer.submit()
+            # the de-interleaved frame is what a step delivers; the previous step's is put
+            # together while this step's gather runs
+            if mode == "gather" and rank == 0 and prev[0] is not None:
+                gatherer.frame(prev[0])
+            prev[0] = slot
+            if timed.index() >= 0:
+                rays_done[0] += my_rays
+            timed.step_no += 1
+            return slot
+
+    elif mode == "strips":
+        from raytracer_amd.device import BatchPlan
+
+        frames_per_step = world
+        renders_per_launch = world
+        plans = {}
+
+        def render_strips(slot, params, outs):
+            if slot not in plans:
+                plans[slot] = BatchPlan([tracer] * world, [params] * world, [o.data_ptr() for o in outs])
+            timed.launch(lambda: plans[slot].launch(stream.cuda_stream))
+
+        gatherer = strips.StripExchange(base, render_strips, device)
+
+        prev = [None]
+
+        def step():
+            slot = gatherer.submit()
+            if prev[0] is not None:
+                gatherer.frame(prev[0])  # this rank's frame of the previous batch, re-assembled
+            prev[0] = slot
+            if timed.index() >= 0:
+                rays_done[0] += my_rays * world  # this rank's strip of each of the N frames
+            timed.step_no += 1
+            return slot
+
+    else:  # batch: this rank's frames are different views of the scene, uploaded before the clock starts
+        from raytracer_amd.device import DeviceTracer
+
+        frames_per_step = world
+        n_views = 8
+        views, view_rays, view_flops = [], [], []
+        for v in range(n_views):
+            t = DeviceTracer(ctx["local_rank"])
+            pr, lt = scenes.orbit_scene(prims, lights, 2 * math.pi * (rank * n_views + v) / (world * n_views))
+            t.upload_scene(pr, lt)
+            d_cnt.zero_()
+            t.render_device(pc, stream.cuda_stream, scratch.data_ptr(), d_counters=d_cnt.data_ptr())
+            torch.cuda.synchronize()
+            c = d_cnt.cpu().numpy().astype(np.uint64)
+            view_rays.append(int(c[0]))
+            view_flops.append(algorithmic_flops({f: int(c[i]) for i, f in enumerate(abi.COUNTER_FIELDS)}, height * width))
+            views.append(t)
+        my_flops = float(np.mean(view_flops))
+        out = [torch.zeros((height, width, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+
+        def step():
+            v = timed.step_no % n_views
+            timed.launch(lambda: views[v].render_device(base, stream.cuda_stream, out[timed.step_no & 1].data_ptr()))
+            if timed.index() >= 0:
+                rays_done[0] += view_rays[v]
+            timed.step_no += 1
+            return 0
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if gatherer is not None:
+        gatherer.drain()
+    fence()
+    t0 = time.perf_counter()
+    last = 0
+    for _ in range(args.steps):
+        last = step()
+    if gatherer is not None:
+        gatherer.drain()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays_done[0]], dtype=torch.int64, device=device)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays_total = int(r.item())
+    else:
+        rays_total = rays_done[0]
+
+    if rank == 0 and args.dump and gatherer is not None:
+        from raytracer_amd.frame import write_bmp
+
+        write_bmp(args.dump, gatherer.frame(last).cpu().numpy())
+    return {
+        "mode": mode,
+        "scaling": scaling,
+        "frames_per_step": frames_per_step,
+        "elapsed": elapsed,
+        "rays_total": rays_total,
+        "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+        "value": rays_total / elapsed / 1e6,
+        "kernel_ms": timed.kernel_ms(),
+        "flops_per_launch": my_flops * renders_per_launch,
+        "fb_bytes": my_rows * renders_per_launch * width * 3,
+        "batched": mode == "strips",
+    }
+
+
+def end_to_end(tracer, prims, lights, base, cpu_ms_per_frame):
+    """rt_render (render + copy to the host) of the workload's frame, and the whole program."""
+    from raytracer_amd.device import HostFrame
+    from raytracer_amd.frame import write_bmp
+
+    w, h, d = int(base["width"]), int(base["height"]), int(base["max_depth"])
+    out = {}
+
+    def time_into(arr, n=12):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            tracer.render_into(base, arr)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts[2:])), float(min(ts[2:]))
+
+    pageable = np.zeros((h, w, 3), dtype=np.uint8)
+    med, lo = time_into(pageable)
+    out["rt_render_ms_pageable"] = med
+    hf = HostFrame((h, w, 3))
+    med, lo = time_into(hf.array)
+    out["rt_render_ms_page_locked"] = med
+    out["rt_render_ms_page_locked_min"] = lo
+    hf.close()
+    if cpu_ms_per_frame:
+        out["cpu_port_ms_per_frame"] = cpu_ms_per_frame
+        out["rt_render_page_locked_over_cpu_port"] = cpu_ms_per_frame / out["rt_render_ms_page_locked"]
+        out["rt_render_pageable_over_cpu_port"] = cpu_ms_per_frame / out["rt_render_ms_pageable"]
+    # the whole program, as the reference times it (src/main.cc:211,236-238): screen, scene,
+    # Tracer, present (here: BMP file).  GPU side: the C++ host program; CPU side: the port.
+    exe = os.path.join(ROOT, "raytracer_amd", "host", "rt_main")
+    with tempfile.TemporaryDirectory() as tmp:
+        if os.path.exists(exe):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "--width", str(w), "--height", str(h), "--depth", str(d), "--out",
+                                os.path.join(tmp, "gpu.bmp")], capture_output=True, text=True, timeout=300)
+            wall = time.perf_counter() - t0
+            if r.returncode == 0:
+                out["main_equivalent_s_gpu_process_wall"] = wall
+                for line in r.stdout.splitlines():
+                    if line.startswith("Time:"):
+                        out["main_equivalent_s_gpu"] = float(line.split()[1])
+                    if line.startswith("Tracer:"):
+                        out["tracer_call_s_gpu"] = float(line.split()[1])
+        if cpu_ms_per_frame:
+            from tests import oracle_lib
+
+            t0 = time.perf_counter()
+            r = oracle_lib.render(prims, lights, base, want_ids=False, want_masks=False)
+            write_bmp(os.path.join(tmp, "cpu.bmp"), r["bgr"])
+            out["main_equivalent_s_cpu_port"] = time.perf_counter() - t0
+    return out
+
+
+def extra_workload(name, torch, device, stream, local_rank, steps=3, warmup=1, cpu_budget_s=6.0):
+    """A few steps of another workload on this GPU, with its own roofline and CPU sample."""
+    from raytracer_amd.device import DeviceTracer
+
+    builder, width, height, depth = WORKLOADS[name]
+    prims, lights = builder()
+    base = abi.make_params(width, height, depth)
+    tracer = DeviceTracer(local_rank)
+    tracer.upload_scene(prims, lights)
+    out = torch.zeros((height, width, 3), dtype=torch.uint8, device=device)
+    d_cnt = torch.zeros(8, dtype=torch.int64, device=device)
+    pc = base.copy()
+    pc["flags"] = abi.RT_FLAG_COUNTERS
+    tracer.render_device(pc, stream.cuda_stream, out.data_ptr(), d_counters=d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    c = d_cnt.cpu().numpy().astype(np.uint64)
+    counters = {f: int(c[i]) for i, f in enumerate(abi.COUNTER_FIELDS)}
+    flops = algorithmic_flops(counters, width * height)
+    for _ in range(warmup):
+        tracer.render_device(base, stream.cuda_stream, out.data_ptr())
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        tracer.render_device(base, stream.cuda_stream, out.data_ptr())
+        b.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kms = [a.elapsed_time(b) for a, b in ev]
+    rec = {
+        "workload": f"{name}: {width}x{height}, max_depth {depth}, {len(prims)} objects, {len(lights)} lights",
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "value": counters["rays"] * steps / elapsed / 1e6,
+        "unit": "Mrays/s",
+        "rays_per_step": counters["rays"],
+        "roofline": roofline(prims, lights, depth, False, flops, kms, width * height * 3, name),
+        "cpu_baseline": cpu_baseline(prims, lights, base, budget_s=cpu_budget_s),
+    }
+    rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+    tracer.close()
+    return rec
 
 
 def main():
@@ -160,9 +503,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--mode", choices=("strips", "gather", "batch"), default="strips")
+    ap.add_argument("--mode", choices=("all", "strips", "gather", "batch"), default="all")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="default_4k_d5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="N=1: skip the 1024-sphere and glass workloads")
+    ap.add_argument("--no-end-to-end", action="store_true", help="N=1: skip the rt_render / rt_main timings")
     ap.add_argument("--dump", default=None, help="rank 0: write the last frame as BMP to this path")
     args = ap.parse_args()
 
@@ -198,201 +543,62 @@ def main():
     tracer = DeviceTracer(local_rank)
     tracer.upload_scene(prims, lights)
     stream = torch.cuda.current_stream()
+    ctx = dict(torch=torch, dist=dist, world=world, rank=rank, local_rank=local_rank, device=device, stream=stream,
+               tracer=tracer, base=base, args=args, prims=prims, lights=lights)
 
-    # ---- what this rank renders per step ------------------------------------------------
     if world == 1:
-        mode, scaling, frames_per_step = "single", "weak", 1
-        my = base.copy()
-    elif args.mode == "strips":
-        mode, scaling, frames_per_step = "strips", "weak", world
-        my = strips.rank_params(base, rank, world)
-    elif args.mode == "gather":
-        mode, scaling, frames_per_step = "gather", "strong", 1
-        my = strips.rank_params(base, rank, world)
+        modes = ["single"]
+    elif args.mode == "all":
+        modes = ["batch", "gather", "strips"]  # `value` comes from the first one
     else:
-        mode, scaling, frames_per_step = "batch", "weak", world
-        my = base.copy()
-    my_rows = abi.strip_rows(my)
-
-    # untimed counter launch: rays and event counts of this rank's share of one frame
-    d_cnt = torch.zeros(8, dtype=torch.int64, device=device)
-    scratch = torch.zeros((max(my_rows, 1), width, 3), dtype=torch.uint8, device=device)
-    pc = my.copy()
-    pc["flags"] = abi.RT_FLAG_COUNTERS
-    tracer.render_device(pc, stream.cuda_stream, scratch.data_ptr(), d_counters=d_cnt.data_ptr())
-    torch.cuda.synchronize()
-    cnt_host = d_cnt.cpu().numpy().astype(np.uint64)
-    counters = {f: int(cnt_host[i]) for i, f in enumerate(abi.COUNTER_FIELDS)}
-    my_flops = algorithmic_flops(counters, my_rows * width)  # of ONE launch of this rank
-    my_rays = counters["rays"]
-
-    # HIP events around the launches of every timed step, on the streams they run on
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    step_no = [0]
-    rays_done = [0]  # rays this rank traced in the timed steps
-    renders_per_launch = world if mode == "strips" else 1  # strips: one batched launch of N strips
-
-    def timed(i):
-        return 0 <= i < args.steps
-
-    if mode in ("single", "gather"):
-
-        def render_strip(params, out):
-            i = step_no[0] - args.warmup
-            if timed(i):
-                ev[i][0].record(stream)
-            tracer.render_device(params, stream.cuda_stream, out.data_ptr())
-            if timed(i):
-                ev[i][1].record(stream)
-
-        gatherer = strips.StripGatherer(base, render_strip, device)
-
-        def step():
-            slot = gatherer.submit()
-            if timed(step_no[0] - args.warmup):
-                rays_done[0] += my_rays
-            step_no[0] += 1
-            return slot
-
-    elif mode == "strips":
-        # one batched launch per step: this rank's strip of each of the N frames
-        from raytracer_amd.device import BatchPlan
-
-        plans = {}
-
-        def render_strips(slot, params, outs):
-            i = step_no[0] - args.warmup
-            if slot not in plans:
-                plans[slot] = BatchPlan([tracer] * world, [params] * world, [o.data_ptr() for o in outs])
-            if timed(i):
-                ev[i][0].record(stream)
-            plans[slot].launch(stream.cuda_stream)
-            if timed(i):
-                ev[i][1].record(stream)
-
-        gatherer = strips.StripExchange(base, render_strips, device)
-
-        def step():
-            slot = gatherer.submit()
-            if timed(step_no[0] - args.warmup):
-                rays_done[0] += my_rays * world  # this rank's strip of each of the N frames
-            step_no[0] += 1
-            return slot
-
-    else:
-        # orbit batch: this rank's frames are different views of the scene; the scene of
-        # every view is uploaded before the clock starts.
-        gatherer = None
-        n_views = 8
-        views, view_rays = [], []
-        for v in range(n_views):
-            t = DeviceTracer(local_rank)
-            pr, lt = scenes.orbit_scene(prims, lights, 2 * math.pi * (rank * n_views + v) / (world * n_views))
-            t.upload_scene(pr, lt)
-            d_cnt.zero_()
-            t.render_device(pc, stream.cuda_stream, scratch.data_ptr(), d_counters=d_cnt.data_ptr())
-            torch.cuda.synchronize()
-            view_rays.append(int(d_cnt[0].item()))
-            views.append(t)
-        out = [torch.zeros((height, width, 3), dtype=torch.uint8, device=device) for _ in range(2)]
-
-        def step():
-            i = step_no[0] - args.warmup
-            if timed(i):
-                ev[i][0].record(stream)
-            views[step_no[0] % n_views].render_device(base, stream.cuda_stream, out[step_no[0] & 1].data_ptr())
-            if timed(i):
-                ev[i][1].record(stream)
-                rays_done[0] += view_rays[step_no[0] % n_views]
-            step_no[0] += 1
-            return 0
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    if gatherer is not None:
-        gatherer.drain()
-    fence()
-    t0 = time.perf_counter()
-    last = 0
-    for _ in range(args.steps):
-        last = step()
-    if gatherer is not None:
-        gatherer.drain()
-    fence()
-    elapsed = time.perf_counter() - t0
-
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
-    my_flops *= renders_per_launch
-    my_rows *= renders_per_launch
-
-    # max over ranks of the wall time, sum over ranks of the rays
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        r = torch.tensor([rays_done[0]], dtype=torch.int64, device=device)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays_total = int(r.item())
-    else:
-        rays_total = rays_done[0]
+        modes = [args.mode]
+    results = [run_mode(m, ctx) for m in modes]
 
     if rank == 0:
-        if args.dump and gatherer is not None:
-            from raytracer_amd.frame import write_bmp
-
-            write_bmp(args.dump, gatherer.frame(last).cpu().numpy())
-        ms_per_step = elapsed / args.steps * 1e3
-        value = rays_total / elapsed / 1e6
-        achieved = my_flops / (kernel_ms * 1e-3) / 1e12
-        fb_bytes = my_rows * width * 3
+        head = results[0]
         line = {
             "metric": "Mrays/s (primary+secondary rays traced)",
-            "value": value,
+            "value": head["value"],
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
-            "scaling": scaling,
+            "scaling": head["scaling"],
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {width}x{height}, max_depth {depth}, {len(prims)} objects, "
                             f"{len(lights)} lights",
-                "mode": mode,
+                "mode": head["mode"],
                 "backend": (dist.get_backend() if world > 1 else None),
-                "frames_per_step": frames_per_step,
-                "rays_per_step": rays_total / max(args.steps, 1),
+                "frames_per_step": head["frames_per_step"],
+                "rays_per_step": head["rays_total"] / max(args.steps, 1),
                 "band_rows": strips.DEFAULT_BAND_ROWS,
             },
-            "roofline": {
-                "bound": "valu",
-                "achieved": achieved,
-                "peak": PEAK_FP64_VALU_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP64_VALU_TFLOPS,
-                "frac_of_fp32_packed_peak": achieved / PEAK_FP32_PACKED_VALU_TFLOPS,
-                "traffic": _traffic_bytes(args.workload) if world == 1 else None,
-                # template arguments: mask words, counters, sphere tree, deep stack
-                "kernel": ("whitted_batch_kernel<%s,%s>" if mode == "strips" else "whitted_kernel<0,false,%s,%s>")
-                % (("true" if len(prims) - int((prims["type"] == abi.RT_PRIM_PLANE).sum()) >= 40 else "false"),
-                   ("true" if depth > 5 else "false")),
-                "kernel_ms": kernel_ms,
-                "algorithmic_flops_per_launch": my_flops,
-                "framebuffer_write_GBps": fb_bytes / (kernel_ms * 1e-3) / 1e9,
-            },
+            "roofline": roofline(prims, lights, depth, head["batched"], head["flops_per_launch"], head["kernel_ms"],
+                                 head["fb_bytes"], args.workload, with_profile=(world == 1)),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(prims, lights, base)
-            line["config"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        if world > 1:
+            line["modes"] = {
+                r["mode"]: {
+                    "value": r["value"], "unit": "Mrays/s", "ms_per_step": r["ms_per_step"], "scaling": r["scaling"],
+                    "frames_per_step": r["frames_per_step"], "kernel_ms_rank0": float(np.mean(r["kernel_ms"])),
+                }
+                for r in results
+            }
+        if world == 1:
+            cpu_ms = None
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(prims, lights, base)
+                line["config"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+                cpu_ms = line["cpu_baseline"]["ms_per_frame"]
+            if not args.no_end_to_end:
+                line["end_to_end"] = end_to_end(tracer, prims, lights, base, cpu_ms)
+            if not args.no_extra and args.workload == "default_4k_d5":
+                line["extra"] = {n: extra_workload(n, torch, device, stream, local_rank) for n in EXTRA_WORKLOADS}
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -20,6 +20,7 @@
 #ifndef RT_HIP_H
 #define RT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -51,10 +52,11 @@ extern "C" {
  */
 typedef struct rt_prim {
     int32_t type;             /* RT_PRIM_PLANE | RT_PRIM_SPHERE                           */
-    int32_t reserved;         /* must be 0                                               */
+    int32_t reserved;         /* must be 0 (RT_ERR_ARG otherwise)                        */
     double p[3];              /* plane: origin_ ; sphere: center_                        */
     double q[3];              /* plane: normal_ AS STORED, i.e. after the constructor's
-                                 makeNormal (src/objects.h:88); sphere: {radius_, 0, 0},
+                                 makeNormal (src/objects.h:88): of unit length to 1e-12
+                                 (or all zero), RT_ERR_ARG otherwise; sphere: {radius_, 0, 0},
                                  radius_ already widened from the constructor's float
                                  (src/objects.h:116,146)                                 */
     double kd[3];             /* material().kd r,g,b (ka and ks are never read)          */
@@ -138,6 +140,28 @@ const char* rt_version(void);
 int rt_create(int32_t device_id, rt_ctx** out);
 void rt_destroy(rt_ctx* ctx);
 
+/* No entry point changes the calling thread's current HIP device: each one makes the
+ * context's device current for the duration of the call and puts the caller's back.       */
+
+/*
+ * Device memory a context holds besides the scene and the staging buffers of rt_render
+ * (which grow to the largest frame rendered): renders with max_depth > 5 keep part of their
+ * ray stacks in a workspace of 48 MiB (256 CUs), one per stream such a render was enqueued
+ * on, allocated at the first such render on that stream.  rt_trim() waits for the device to
+ * go idle and frees these workspaces (a later render allocates afresh); a caller that
+ * creates streams freely calls it now and then.  No counterpart in the reference.
+ */
+int rt_trim(rt_ctx* ctx);
+
+/*
+ * Page-locked host memory for frames (hipHostMalloc, usable with every device): rt_render
+ * and rt_render_node copy into such a buffer at the full PCIe rate, into ordinary memory at
+ * about a third of it.  Errors are reported by rt_last_error(NULL).  No counterpart in the
+ * reference, whose Screen allocates its buffers with new[] (src/screen.h:24-33).
+ */
+int rt_host_alloc(size_t bytes, void** out);
+void rt_host_free(void* p);
+
 /* Last error text of `ctx` (or of rt_create when ctx is NULL).  Never NULL.             */
 const char* rt_last_error(const rt_ctx* ctx);
 
@@ -166,7 +190,9 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims,
  *   counters   filled when RT_FLAG_COUNTERS is set                            nullable
  * Replaces Tracer() + Screen::StorePixel for the rows of the partition.
  * The copies run at the full PCIe rate when the host buffers are page-locked
- * (hipHostMalloc / hipHostRegister), at about a third of it otherwise.
+ * (rt_host_alloc, hipHostMalloc, hipHostRegister), at about a third of it otherwise.  With
+ * only `bgr` asked for, the partition is rendered in up to 8 parts and each part is copied
+ * while the next one is rendered.
  */
 int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id,
               uint32_t* hit_mask, uint32_t* spawn_mask, rt_counters* counters);
@@ -193,6 +219,19 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
  */
 int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t n,
                            void* stream, uint8_t* const* d_bgr);
+
+/*
+ * One frame on the n GPUs of a node from ONE host thread: Tracer() (src/main.cc:115-141) with
+ * its row loop (src/main.cc:130) dealt out in bands of `band_rows` rows, band b to
+ * ctxs[b mod n].  Every context (each on its own device, or several on one) must hold the
+ * scene; `p` describes the frame (its band_* fields are ignored).  Each device renders its
+ * bands in a few parts and copies every part straight into the rows it covers in `bgr`
+ * (height*width*3 bytes on the host, row 0 = bottom scanline) while it renders the next, so
+ * the n PCIe links work side by side and nothing is re-assembled afterwards.  Blocking.
+ * Image only (no RT_FLAG_COUNTERS).  Errors are reported on ctxs[0].
+ */
+int rt_render_node(rt_ctx* const* ctxs, int32_t n, const rt_params* p, int32_t band_rows,
+                   uint8_t* bgr);
 
 /*
  * Test hooks: run the device versions of the reference's collision tests and of the

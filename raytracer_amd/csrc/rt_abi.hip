@@ -1,6 +1,7 @@
 // C ABI of the tracer (include/rt_hip.h): context, scene upload, render, test hooks.
 // Host code only; the kernels live in whitted_kernels.hip.
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -45,13 +46,19 @@ struct rt_ctx {
     int32_t ltab_stride = 0;
     // grow-only device staging for rt_render's host outputs
     DevBuf bgr, hit_id, hit_mask, spawn_mask, counters, dbg_in, dbg_t, dbg_hit, dbg_unit;
-    // global part of the per-lane stacks (deep recursion only): one workspace per stream
-    // the context has rendered on, since launches on one stream run one after the other
-    // but launches on different streams may overlap.  Grow-only; a buffer that was
-    // outgrown is kept until rt_destroy (an earlier launch may still be using it).
-    std::map<void*, DevBuf> gstack;
-    std::vector<void*> gstack_retired;
+    // workspace of deep-stack launches (max_depth > 5: tile queue + the global part of the
+    // per-lane stacks): one per stream the context has made such a launch on, since
+    // launches on one stream run one after the other but launches on different streams may
+    // overlap.  Its size depends on the device only (workspace_bytes), never on the frame;
+    // rt_trim() frees them all.
+    std::map<void*, void*> workspaces;
+    size_t workspace_bytes = 0;
     hipStream_t stream = nullptr;
+    // rt_render / rt_render_node: second stream and events that let the copy of one part of
+    // a frame run while the next part is rendered
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> part_done;
+    hipEvent_t copies_done = nullptr;
 };
 
 namespace {
@@ -66,6 +73,24 @@ int hip_fail(rt_ctx* ctx, hipError_t e, const char* what) {
     int code = (e == hipErrorOutOfMemory) ? RT_ERR_NOMEM : RT_ERR_HIP;
     return fail(ctx, code, msg);
 }
+
+// Makes `device` current for the lifetime of the object and puts the caller's device back
+// afterwards: the entry points must not change the calling thread's current device.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t status = hipSuccess;
+    explicit DeviceGuard(int device) {
+        status = hipGetDevice(&prev);
+        if (status != hipSuccess) { prev = -1; return; }
+        if (prev != device) status = hipSetDevice(device);
+        else prev = -1;  // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 #define RT_HIP_TRY(ctx, call)                                 \
     do {                                                      \
@@ -92,24 +117,32 @@ int check_params(const rt_params* p) {
     return RT_OK;
 }
 
+// The deep-stack workspace of `stream` (allocated at the first deep launch on that stream).
+int stream_workspace(rt_ctx* ctx, void* stream, void** out) {
+    void*& w = ctx->workspaces[stream];
+    if (!w) RT_HIP_TRY(ctx, hipMalloc(&w, ctx->workspace_bytes));
+    *out = w;
+    return RT_OK;
+}
+
+// Point the arguments of a deep-stack launch at workspace `ws` and clear its tile queue on
+// `stream`; returns the grid size of the launch (0 when the depth needs no workspace).
+int attach_workspace(rt_ctx* ctx, rt::KArgs* args, int n, long long tiles, int max_depth, void* ws, hipStream_t stream,
+                     int* deep_blocks) {
+    *deep_blocks = 0;
+    if (rt::stack_global_entries(max_depth) == 0) return RT_OK;
+    *deep_blocks = rt::deep_grid_blocks(ctx->n_cus, tiles);
+    for (int i = 0; i < n; ++i) {
+        args[i].tile_queue = static_cast<unsigned int*>(ws);
+        args[i].gstack = reinterpret_cast<double*>(static_cast<char*>(ws) + rt::kWorkspaceHeader);
+    }
+    RT_HIP_TRY(ctx, hipMemsetAsync(ws, 0, rt::kWorkspaceHeader, stream));
+    return RT_OK;
+}
+
 // Fill the kernel arguments for the partition in p.  The camera arithmetic is the
 // ViewFrustum constructor's (src/view_frustum.h:18,28-34), evaluated on the host in
 // double exactly as written there.
-// The stack workspace of `stream`, at least `bytes` large (*out = null when bytes is 0).
-int reserve_gstack(rt_ctx* ctx, void* stream, size_t bytes, void** out) {
-    *out = nullptr;
-    if (bytes == 0) return RT_OK;
-    DevBuf& b = ctx->gstack[stream];
-    if (bytes > b.cap) {
-        void* fresh = nullptr;
-        RT_HIP_TRY(ctx, hipMalloc(&fresh, bytes));
-        if (b.ptr) ctx->gstack_retired.push_back(b.ptr);
-        b.ptr = fresh;
-        b.cap = bytes;
-    }
-    *out = b.ptr;
-    return RT_OK;
-}
 
 // The tree pays once a ray has more spheres to test than a walk visits nodes.
 constexpr int kTreeMinSpheres = 40;
@@ -202,8 +235,12 @@ int rt_create(int32_t device_id, rt_ctx** out) {
     if (!ctx) return fail(nullptr, RT_ERR_NOMEM, "rt_create: out of host memory");
     ctx->device = device_id;
     ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    e = hipSetDevice(device_id);
+    ctx->workspace_bytes = rt::stack_workspace_bytes(RT_MAX_DEPTH, rt::deep_grid_blocks(ctx->n_cus, 1LL << 40));
+    DeviceGuard guard(device_id);
+    e = guard.status;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copies_done, hipEventDisableTiming);
     if (e != hipSuccess) {
         rt_destroy(ctx);
         return hip_fail(nullptr, e, "rt_create: device set-up");
@@ -212,26 +249,56 @@ int rt_create(int32_t device_id, rt_ctx** out) {
     return RT_OK;
 }
 
+static void free_workspaces(rt_ctx* ctx) {
+    for (auto& kv : ctx->workspaces)
+        if (kv.second) (void)hipFree(kv.second);
+    ctx->workspaces.clear();
+}
+
 void rt_destroy(rt_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    DevBuf* bufs[] = {&ctx->bgr, &ctx->hit_id, &ctx->hit_mask, &ctx->spawn_mask, &ctx->counters,
-                      &ctx->dbg_in, &ctx->dbg_t, &ctx->dbg_hit, &ctx->dbg_unit};
-    for (DevBuf* b : bufs)
-        if (b->ptr) (void)hipFree(b->ptr);
-    if (ctx->d_geom) (void)hipFree(ctx->d_geom);
-    if (ctx->d_mat) (void)hipFree(ctx->d_mat);
-    if (ctx->d_lights) (void)hipFree(ctx->d_lights);
-    if (ctx->f_geom) (void)hipFree(ctx->f_geom);
-    if (ctx->f_tree) (void)hipFree(ctx->f_tree);
-    if (ctx->f_planes) (void)hipFree(ctx->f_planes);
-    if (ctx->d_planes_before) (void)hipFree(ctx->d_planes_before);
-    if (ctx->d_ltab) (void)hipFree(ctx->d_ltab);
-    for (auto& kv : ctx->gstack)
-        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
-    for (void* q : ctx->gstack_retired) (void)hipFree(q);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    {
+        DeviceGuard guard(ctx->device);
+        DevBuf* bufs[] = {&ctx->bgr, &ctx->hit_id, &ctx->hit_mask, &ctx->spawn_mask, &ctx->counters,
+                          &ctx->dbg_in, &ctx->dbg_t, &ctx->dbg_hit, &ctx->dbg_unit};
+        for (DevBuf* b : bufs)
+            if (b->ptr) (void)hipFree(b->ptr);
+        if (ctx->d_geom) (void)hipFree(ctx->d_geom);
+        if (ctx->d_mat) (void)hipFree(ctx->d_mat);
+        if (ctx->d_lights) (void)hipFree(ctx->d_lights);
+        if (ctx->f_geom) (void)hipFree(ctx->f_geom);
+        if (ctx->f_tree) (void)hipFree(ctx->f_tree);
+        if (ctx->f_planes) (void)hipFree(ctx->f_planes);
+        if (ctx->d_planes_before) (void)hipFree(ctx->d_planes_before);
+        if (ctx->d_ltab) (void)hipFree(ctx->d_ltab);
+        free_workspaces(ctx);
+        for (hipEvent_t ev : ctx->part_done) (void)hipEventDestroy(ev);
+        if (ctx->copies_done) (void)hipEventDestroy(ctx->copies_done);
+        if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    }
     delete ctx;
+}
+
+int rt_trim(rt_ctx* ctx) {
+    if (!ctx) return RT_ERR_ARG;
+    DeviceGuard guard(ctx->device);
+    RT_HIP_TRY(ctx, guard.status);
+    RT_HIP_TRY(ctx, hipDeviceSynchronize());  // a launch may still be using a workspace
+    free_workspaces(ctx);
+    return RT_OK;
+}
+
+int rt_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return fail(nullptr, RT_ERR_ARG, "rt_host_alloc: bad argument");
+    *out = nullptr;
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipHostMalloc");
+    return RT_OK;
+}
+
+void rt_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -248,6 +315,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         const rt_prim& s = prims[i];
         if (s.type != RT_PRIM_PLANE && s.type != RT_PRIM_SPHERE)
             return fail(ctx, RT_ERR_ARG, "rt_upload_scene: unknown primitive type");
+        if (s.reserved != 0) return fail(ctx, RT_ERR_ARG, "rt_upload_scene: rt_prim.reserved must be 0");
         rt::DGeom& g = geom[i];
         rt::DMat& m = mat[i];
         std::memset(&g, 0, sizeof g);
@@ -265,6 +333,15 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         for (int c = 0; c < 3; ++c)
             if (!std::isfinite(s.p[c]) || !std::isfinite(s.q[c]))
                 return fail(ctx, RT_ERR_ARG, "rt_upload_scene: non-finite position, normal or radius");
+        // A plane's normal is the unit vector its constructor stores (src/objects.h:88): the
+        // error bounds of the single-precision filters are derived for |normal| = 1.  The
+        // zero vector (what gmtl's normalisation leaves of a zero normal) is accepted too.
+        if (s.type == RT_PRIM_PLANE) {
+            const double n2 = s.q[0] * s.q[0] + s.q[1] * s.q[1] + s.q[2] * s.q[2];
+            if (n2 != 0.0 && std::fabs(n2 - 1.0) > 1e-12)
+                return fail(ctx, RT_ERR_ARG, "rt_upload_scene: plane normal is not of unit length (pass normal_ as "
+                                             "stored by the Plane constructor)");
+        }
         g.transparency = s.transparency;
         m.reflectivity = s.reflectivity;
         m.transparency = s.transparency;
@@ -352,7 +429,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
     std::vector<rt::FGeom> tree = rt::build_sphere_tree(tsph, &tree_extent1);
     // the filter's per-ray error bound must cover the boxes too
     if (static_cast<float>(tree_extent1) * 1.0001f > p1max) p1max = static_cast<float>(tree_extent1) * 1.0001f;
-    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard(ctx->device);
+    RT_HIP_TRY(ctx, guard.status);
     ctx->have_scene = false;
     if (ctx->f_geom) RT_HIP_TRY(ctx, hipFree(ctx->f_geom));
     ctx->f_geom = nullptr;
@@ -397,10 +475,11 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
     return RT_OK;
 }
 
-int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_bgr, int32_t* d_hit_id,
-                     uint32_t* d_hit_mask, uint32_t* d_spawn_mask, rt_counters* d_counters) {
-    if (!ctx) return RT_ERR_ARG;
-    if (!d_bgr) return fail(ctx, RT_ERR_ARG, "rt_render_device: d_bgr is null");
+// Enqueue one render with device outputs on `stream`; the deep-stack workspace is `ws` when
+// given and this stream's own otherwise.  The caller has made the
+// context's device current.
+static int enqueue_render(rt_ctx* ctx, const rt_params* p, hipStream_t stream, void* ws, uint8_t* d_bgr,
+                          int32_t* d_hit_id, uint32_t* d_hit_mask, uint32_t* d_spawn_mask, rt_counters* d_counters) {
     rt::KArgs a;
     int rc = make_args(ctx, p, a);
     if (rc != RT_OK) return rc;
@@ -412,13 +491,25 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
     a.spawn_mask = d_spawn_mask;
     a.counters = reinterpret_cast<unsigned long long*>(d_counters);
     const bool emit = d_hit_id || d_hit_mask || d_spawn_mask;
-    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    void* ws = nullptr;
-    if ((rc = reserve_gstack(ctx, stream, rt::stack_global_bytes(a.max_depth, a.tiles_x, a.tiles_y), &ws)) != RT_OK)
-        return rc;
-    a.gstack = static_cast<double*>(ws);
-    RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, use_tree(ctx, p), static_cast<hipStream_t>(stream)));
+    int deep_blocks = 0;
+    if (a.tiles_x > 0 && a.tiles_y > 0 && rt::stack_global_entries(a.max_depth) > 0) {
+        if (!ws && (rc = stream_workspace(ctx, stream, &ws)) != RT_OK) return rc;
+        if ((rc = attach_workspace(ctx, &a, 1, static_cast<long long>(a.tiles_x) * a.tiles_y, a.max_depth, ws, stream,
+                                   &deep_blocks)) != RT_OK)
+            return rc;
+    }
+    RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, use_tree(ctx, p), deep_blocks, stream));
     return RT_OK;
+}
+
+int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_bgr, int32_t* d_hit_id,
+                     uint32_t* d_hit_mask, uint32_t* d_spawn_mask, rt_counters* d_counters) {
+    if (!ctx) return RT_ERR_ARG;
+    if (!d_bgr) return fail(ctx, RT_ERR_ARG, "rt_render_device: d_bgr is null");
+    DeviceGuard guard(ctx->device);
+    RT_HIP_TRY(ctx, guard.status);
+    return enqueue_render(ctx, p, static_cast<hipStream_t>(stream), nullptr, d_bgr, d_hit_id, d_hit_mask, d_spawn_mask,
+                          d_counters);
 }
 
 int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t n, void* stream,
@@ -436,56 +527,216 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
             return fail(first, RT_ERR_ARG, "rt_render_device_batch: scenes with and without a sphere tree in one batch");
     }
     const bool tree = use_tree(first, &params[0]);
-    RT_HIP_TRY(first, hipSetDevice(first->device));
+    DeviceGuard guard(first->device);
+    RT_HIP_TRY(first, guard.status);
     for (int base = 0; base < n; base += rt::kMaxBatch) {
         const int m = (n - base < rt::kMaxBatch) ? n - base : rt::kMaxBatch;
         rt::KBatch b;
         std::memset(&b, 0, sizeof b);
-        size_t goff[rt::kMaxBatch + 1] = {0};
+        int depth = 0, live = 0;
+        long long tiles = 0;
         for (int i = 0; i < m; ++i) {
-            int rc = make_args(ctxs[base + i], &params[base + i], b.a[i]);
+            rt::KArgs a;
+            int rc = make_args(ctxs[base + i], &params[base + i], a);
             if (rc != RT_OK) {
                 if (ctxs[base + i] != first) first->err = ctxs[base + i]->err;
                 return rc;
             }
-            b.a[i].bgr = d_bgr[base + i];
-            goff[i + 1] = goff[i] + rt::stack_global_bytes(b.a[i].max_depth, b.a[i].tiles_x, b.a[i].tiles_y);
+            if (a.tiles_x <= 0 || a.tiles_y <= 0) continue;  // an empty partition
+            a.bgr = d_bgr[base + i];
+            tiles += static_cast<long long>(a.tiles_x) * a.tiles_y;
+            if (tiles > INT32_MAX) return fail(first, RT_ERR_ARG, "rt_render_device_batch: too many tiles in one launch");
+            b.a[live] = a;
+            b.tile_end[live] = static_cast<int32_t>(tiles);
+            depth = a.max_depth > depth ? a.max_depth : depth;
+            ++live;
         }
-        // every render of the launch gets its own part of the first context's workspace
-        void* ws = nullptr;
-        int rcg = reserve_gstack(first, stream, goff[m], &ws);
-        if (rcg != RT_OK) return rcg;
-        for (int i = 0; i < m; ++i)
-            b.a[i].gstack = ws ? reinterpret_cast<double*>(static_cast<char*>(ws) + goff[i]) : nullptr;
-        RT_HIP_TRY(first, rt::launch_whitted_batch(b, m, tree, static_cast<hipStream_t>(stream)));
+        if (live == 0) continue;
+        // the launch uses the first context's workspace of this stream
+        int deep_blocks = 0;
+        if (rt::stack_global_entries(depth) > 0) {
+            void* ws = nullptr;
+            int rcg = stream_workspace(first, stream, &ws);
+            if (rcg == RT_OK)
+                rcg = attach_workspace(first, b.a, live, tiles, depth, ws, static_cast<hipStream_t>(stream), &deep_blocks);
+            if (rcg != RT_OK) return rcg;
+        }
+        RT_HIP_TRY(first, rt::launch_whitted_batch(b, live, tree, deep_blocks, static_cast<hipStream_t>(stream)));
     }
     return RT_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+// A partition cut into consecutive parts (whole bands each), so that the copy of one part
+// to the host can run while the next part is rendered.  Part i holds strip rows
+// [row0, row0 + rows) of the partition it was cut from.
+struct Part {
+    rt_params p;
+    size_t row0, rows;
+};
+constexpr int kMaxParts = 8;
+constexpr size_t kMinPartPixels = 128 * 1024;  // smaller parts cost more in launches than they hide
+
+// reband: a partition of one band may be cut into smaller bands (only when the caller stores
+// the strip packed).
+std::vector<Part> split_partition(const rt_params& p, bool reband) {
+    std::vector<Part> parts;
+    const size_t rows = static_cast<size_t>(rt_strip_rows(&p));
+    const size_t width = static_cast<size_t>(p.width);
+    int want = static_cast<int>(rows * width / kMinPartPixels);
+    if (want > kMaxParts) want = kMaxParts;
+    // bands that really hold rows
+    int nb = 0;
+    for (int b = 0; b < p.band_count; ++b) {
+        if ((static_cast<int64_t>(p.band_first) + static_cast<int64_t>(b) * p.band_step) * p.band_rows >= p.height) break;
+        ++nb;
+    }
+    if (want >= 2 && nb >= 2) {
+        // groups of consecutive bands
+        const int n = want < nb ? want : nb;
+        size_t row0 = 0;
+        for (int j = 0; j < n; ++j) {
+            const int b0 = static_cast<int>(static_cast<int64_t>(nb) * j / n);
+            const int b1 = static_cast<int>(static_cast<int64_t>(nb) * (j + 1) / n);
+            Part q;
+            q.p = p;
+            q.p.band_first = p.band_first + b0 * p.band_step;
+            q.p.band_count = b1 - b0;
+            q.row0 = row0;
+            q.rows = static_cast<size_t>(rt_strip_rows(&q.p));
+            row0 += q.rows;
+            parts.push_back(q);
+        }
+        return parts;
+    }
+    if (reband && want >= 2 && nb == 1 && p.band_first == 0) {
+        // one band from the bottom row on (the whole frame): cut it into bands of whole tile
+        // rows; pixels do not depend on how the rows are grouped
+        size_t per = (rows + want - 1) / want;
+        per = (per + rt::kTile - 1) / rt::kTile * rt::kTile;
+        size_t row0 = 0;
+        for (int j = 0; row0 < rows; ++j) {
+            Part q;
+            q.p = p;
+            q.p.band_rows = static_cast<int32_t>(per);
+            q.p.band_first = j;
+            q.p.band_step = 1;
+            q.p.band_count = 1;
+            q.row0 = row0;
+            q.rows = (rows - row0 < per) ? rows - row0 : per;
+            // the last part is clipped by the frame; a band that ends inside the frame
+            // (rows < height) is clipped here
+            if (static_cast<size_t>(rt_strip_rows(&q.p)) != q.rows) { parts.clear(); break; }
+            row0 += q.rows;
+            parts.push_back(q);
+        }
+        if (!parts.empty()) return parts;
+    }
+    Part whole;
+    whole.p = p;
+    whole.row0 = 0;
+    whole.rows = rows;
+    parts.push_back(whole);
+    return parts;
+}
+
+int part_event(rt_ctx* ctx, size_t i, hipEvent_t* ev) {
+    while (ctx->part_done.size() <= i) {
+        hipEvent_t e = nullptr;
+        RT_HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->part_done.push_back(e);
+    }
+    *ev = ctx->part_done[i];
+    return RT_OK;
+}
+
+// Image-only render of partition `p` into the context's staging buffer, part by part, each
+// part copied to the host as soon as it is done (on the context's second stream).  Strip row
+// r of the partition goes to host + dst_row(r) bytes, where bands are `band_pitch` bytes
+// apart on the host (band_pitch = bytes of one band: the strip is stored packed).  Nothing
+// is waited for: the caller synchronises ctx->copy_stream.
+int enqueue_render_to_host(rt_ctx* ctx, const rt_params& p, uint8_t* host, size_t band_pitch, rt_counters* d_counters) {
+    const size_t width = static_cast<size_t>(p.width);
+    const size_t rows = static_cast<size_t>(rt_strip_rows(&p));
+    if (rows == 0) return RT_OK;
+    int rc;
+    if ((rc = reserve(ctx, ctx->bgr, rows * width * 3 + 4)) != RT_OK) return rc;
+    uint8_t* d_bgr = static_cast<uint8_t*>(ctx->bgr.ptr);
+    const size_t band_bytes = static_cast<size_t>(p.band_rows) * width * 3;
+    const bool packed = band_pitch == band_bytes;
+    const std::vector<Part> parts = split_partition(p, packed);
+    for (size_t i = 0; i < parts.size(); ++i) {
+        const Part& q = parts[i];
+        uint8_t* d_part = d_bgr + q.row0 * width * 3;
+        if ((rc = enqueue_render(ctx, &q.p, ctx->stream, nullptr, d_part, nullptr, nullptr, nullptr, d_counters)) != RT_OK)
+            return rc;
+        hipEvent_t ev;
+        if ((rc = part_event(ctx, i, &ev)) != RT_OK) return rc;
+        RT_HIP_TRY(ctx, hipEventRecord(ev, ctx->stream));
+        RT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ev, 0));
+        if (packed) {
+            RT_HIP_TRY(ctx, hipMemcpyAsync(host + q.row0 * width * 3, d_part, q.rows * width * 3, hipMemcpyDeviceToHost,
+                                           ctx->copy_stream));
+        } else {
+            // whole bands of the part with one strided copy, a clipped last band on its own
+            const size_t band0 = q.row0 / static_cast<size_t>(p.band_rows);  // parts start on band boundaries
+            const size_t full = q.rows / static_cast<size_t>(p.band_rows);
+            const size_t tail = q.rows - full * static_cast<size_t>(p.band_rows);
+            if (full)
+                RT_HIP_TRY(ctx, hipMemcpy2DAsync(host + band0 * band_pitch, band_pitch, d_part, band_bytes, band_bytes, full,
+                                                 hipMemcpyDeviceToHost, ctx->copy_stream));
+            if (tail)
+                RT_HIP_TRY(ctx, hipMemcpyAsync(host + (band0 + full) * band_pitch, d_part + full * band_bytes,
+                                               tail * width * 3, hipMemcpyDeviceToHost, ctx->copy_stream));
+        }
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id, uint32_t* hit_mask,
               uint32_t* spawn_mask, rt_counters* counters) {
     if (!ctx) return RT_ERR_ARG;
     if (!bgr) return fail(ctx, RT_ERR_ARG, "rt_render: bgr is null");
     if (check_params(p) != RT_OK) return fail(ctx, RT_ERR_ARG, "rt_params: value out of range");
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
     if (count && !counters) return fail(ctx, RT_ERR_ARG, "RT_FLAG_COUNTERS set but counters is null");
     const size_t px = static_cast<size_t>(rt_strip_rows(p)) * p->width;
     const size_t words = rt_mask_words(p->max_depth);
-    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard(ctx->device);
+    RT_HIP_TRY(ctx, guard.status);
     int rc;
-    if ((rc = reserve(ctx, ctx->bgr, px * 3 + 4)) != RT_OK) return rc;
-    if (hit_id && (rc = reserve(ctx, ctx->hit_id, px * 4 + 4)) != RT_OK) return rc;
-    if (hit_mask && (rc = reserve(ctx, ctx->hit_mask, px * words * 4 + 4)) != RT_OK) return rc;
-    if (spawn_mask && (rc = reserve(ctx, ctx->spawn_mask, px * words * 4 + 4)) != RT_OK) return rc;
     if (count) {
         if ((rc = reserve(ctx, ctx->counters, sizeof(rt_counters))) != RT_OK) return rc;
         RT_HIP_TRY(ctx, hipMemsetAsync(ctx->counters.ptr, 0, sizeof(rt_counters), ctx->stream));
     }
-    rc = rt_render_device(ctx, p, ctx->stream, static_cast<uint8_t*>(ctx->bgr.ptr),
-                          hit_id ? static_cast<int32_t*>(ctx->hit_id.ptr) : nullptr,
-                          hit_mask ? static_cast<uint32_t*>(ctx->hit_mask.ptr) : nullptr,
-                          spawn_mask ? static_cast<uint32_t*>(ctx->spawn_mask.ptr) : nullptr,
-                          count ? static_cast<rt_counters*>(ctx->counters.ptr) : nullptr);
+    rt_counters* d_counters = count ? static_cast<rt_counters*>(ctx->counters.ptr) : nullptr;
+    if (!hit_id && !hit_mask && !spawn_mask) {
+        // the image alone: rendered in parts, each copied while the next one is rendered
+        const size_t band_bytes = static_cast<size_t>(p->band_rows) * p->width * 3;
+        if ((rc = enqueue_render_to_host(ctx, *p, bgr, band_bytes, d_counters)) != RT_OK) return rc;
+        if (count) {
+            RT_HIP_TRY(ctx, hipMemcpyAsync(counters, ctx->counters.ptr, sizeof(rt_counters), hipMemcpyDeviceToHost, ctx->stream));
+            RT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        RT_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+        return RT_OK;
+    }
+    if ((rc = reserve(ctx, ctx->bgr, px * 3 + 4)) != RT_OK) return rc;
+    if (hit_id && (rc = reserve(ctx, ctx->hit_id, px * 4 + 4)) != RT_OK) return rc;
+    if (hit_mask && (rc = reserve(ctx, ctx->hit_mask, px * words * 4 + 4)) != RT_OK) return rc;
+    if (spawn_mask && (rc = reserve(ctx, ctx->spawn_mask, px * words * 4 + 4)) != RT_OK) return rc;
+    rc = enqueue_render(ctx, p, ctx->stream, nullptr, static_cast<uint8_t*>(ctx->bgr.ptr),
+                        hit_id ? static_cast<int32_t*>(ctx->hit_id.ptr) : nullptr,
+                        hit_mask ? static_cast<uint32_t*>(ctx->hit_mask.ptr) : nullptr,
+                        spawn_mask ? static_cast<uint32_t*>(ctx->spawn_mask.ptr) : nullptr, d_counters);
     if (rc != RT_OK) return rc;
     if (px) {
         RT_HIP_TRY(ctx, hipMemcpyAsync(bgr, ctx->bgr.ptr, px * 3, hipMemcpyDeviceToHost, ctx->stream));
@@ -499,6 +750,51 @@ int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id, ui
         RT_HIP_TRY(ctx, hipMemcpyAsync(counters, ctx->counters.ptr, sizeof(rt_counters), hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
+}
+
+int rt_render_node(rt_ctx* const* ctxs, int32_t n, const rt_params* p, int32_t band_rows, uint8_t* bgr) {
+    if (!ctxs || n < 1 || !ctxs[0]) return RT_ERR_ARG;
+    rt_ctx* first = ctxs[0];
+    if (!bgr) return fail(first, RT_ERR_ARG, "rt_render_node: bgr is null");
+    if (check_params(p) != RT_OK) return fail(first, RT_ERR_ARG, "rt_params: value out of range");
+    if (band_rows < 1) return fail(first, RT_ERR_ARG, "rt_render_node: band_rows must be positive");
+    if (p->flags & RT_FLAG_COUNTERS) return fail(first, RT_ERR_ARG, "rt_render_node: RT_FLAG_COUNTERS is not supported");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return fail(first, RT_ERR_ARG, "rt_render_node: null context");
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return fail(first, RT_ERR_ARG, "rt_render_node: a context is listed twice");
+        if (!ctxs[i]->have_scene) {
+            ctxs[i]->err = "no scene uploaded";
+            return fail(first, RT_ERR_STATE, "rt_render_node: a context has no scene");
+        }
+    }
+    const int nb = (p->height + band_rows - 1) / band_rows;
+    const size_t band_bytes = static_cast<size_t>(band_rows) * p->width * 3;
+    int rc = RT_OK;
+    int started = 0, failed = -1;
+    for (int i = 0; i < n && rc == RT_OK; ++i) {
+        rt_params q = *p;
+        q.band_rows = band_rows;
+        q.band_first = i;
+        q.band_step = n;
+        q.band_count = (i < nb) ? (nb - i + n - 1) / n : 0;
+        DeviceGuard guard(ctxs[i]->device);
+        if (guard.status != hipSuccess) { rc = hip_fail(ctxs[i], guard.status, "hipSetDevice"); failed = i; break; }
+        // band b of the frame starts b * band_bytes into the caller's buffer: this context's
+        // bands are n * band_bytes apart, the first one i * band_bytes in
+        rc = enqueue_render_to_host(ctxs[i], q, bgr + static_cast<size_t>(i) * band_bytes,
+                                    static_cast<size_t>(n) * band_bytes, nullptr);
+        if (rc != RT_OK) failed = i;
+        started = i + 1;
+    }
+    // wait for whatever was started, also after a failure: the caller's buffer is in use
+    for (int i = 0; i < started; ++i) {
+        DeviceGuard guard(ctxs[i]->device);
+        const hipError_t e = (guard.status == hipSuccess) ? hipStreamSynchronize(ctxs[i]->copy_stream) : guard.status;
+        if (e != hipSuccess && rc == RT_OK) { rc = hip_fail(ctxs[i], e, "hipStreamSynchronize"); failed = i; }
+    }
+    if (failed > 0) first->err = ctxs[failed]->err;  // errors are reported on ctxs[0]
+    return rc;
 }
 
 // rt_params that only carry the object-loop mode (the debug hooks read no camera fields).
@@ -520,7 +816,8 @@ int rt_debug_nearest(rt_ctx* ctx, const double* rays, int32_t n, uint32_t flags,
     rt::KArgs a;
     int rc = make_args(ctx, &p, a);
     if (rc != RT_OK) return rc;
-    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard(ctx->device);
+    RT_HIP_TRY(ctx, guard.status);
     const size_t N = static_cast<size_t>(n);
     if ((rc = reserve(ctx, ctx->dbg_in, N * 48)) != RT_OK) return rc;
     if ((rc = reserve(ctx, ctx->dbg_t, N * 8)) != RT_OK) return rc;
@@ -547,7 +844,8 @@ int rt_debug_occluder(rt_ctx* ctx, const double* points, int32_t n, int32_t ligh
     rt::KArgs a;
     int rc = make_args(ctx, &p, a);
     if (rc != RT_OK) return rc;
-    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard(ctx->device);
+    RT_HIP_TRY(ctx, guard.status);
     const size_t N = static_cast<size_t>(n);
     if ((rc = reserve(ctx, ctx->dbg_in, N * 24)) != RT_OK) return rc;
     if ((rc = reserve(ctx, ctx->dbg_t, N * 8)) != RT_OK) return rc;
@@ -570,7 +868,8 @@ int rt_debug_intersect(rt_ctx* ctx, const double* rays, int32_t n, int32_t prim,
     if (!rays || n < 0 || !t_out || !hit_out || prim < 0 || prim >= ctx->n_prims)
         return fail(ctx, RT_ERR_ARG, "rt_debug_intersect: bad argument");
     if (n == 0) return RT_OK;
-    RT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard(ctx->device);
+    RT_HIP_TRY(ctx, guard.status);
     int rc;
     const size_t N = static_cast<size_t>(n);
     if ((rc = reserve(ctx, ctx->dbg_in, N * 48)) != RT_OK) return rc;

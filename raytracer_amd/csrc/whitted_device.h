@@ -67,7 +67,10 @@ struct KArgs {
     const FGeom* tree;         // sphere tree (sphere_tree.h), n_nodes records; null = not used
     const FGeom* planes;       // the planes' filter records, original index in v[6] (bits)
     const int32_t* planes_before;  // [n_prims + 1]: number of planes with a smaller index
-    double* gstack;            // global part of the stack (stack_global_bytes), null if unused
+    double* gstack;            // global part of the stack: one region per wave of the launch
+                               // (stack_workspace_bytes), null if unused
+    unsigned int* tile_queue;  // deep-stack launches: the next tile to hand out (zeroed before
+                               // every launch), null otherwise
     const float* ltab;         // per light, ltab_stride records {c - P (xyz), threshold}: see
                                // line_miss_from_light(); planes carry threshold -inf
     uint8_t* bgr;
@@ -92,8 +95,11 @@ struct KArgs {
 // The walk keeps at most one pending refraction child per tree level 2..max_depth-1, 4 KB
 // per wave and entry.  Entry 0 (pushed by the primary hit) lives in registers, the next
 // kStackLdsEntries in LDS (what bounds the number of resident waves: 8 KB per wave keeps
-// four waves per SIMD), deeper ones in a global-memory workspace with one region per wave
-// of the grid, written and read back by the same wave while it is still in the L2.
+// four waves per SIMD), deeper ones in a global-memory workspace, written and read back by
+// the same wave while it is still in the L2.  A launch that needs the workspace (max_depth
+// > 5) is a fixed grid of at most kDeepMaxBlocks blocks whose waves take 8x8 tiles from a
+// queue (one atomic add per tile) until it is empty, so the workspace holds one region per
+// wave of that grid whatever the frame size: 48 MiB for the full grid at max_depth 8.
 constexpr int kStackLdsEntries = 2;
 __host__ __device__ inline int stack_entries(int max_depth) { return max_depth > 2 ? max_depth - 2 : 0; }
 __host__ __device__ inline int stack_lds_entries(int max_depth) {
@@ -108,23 +114,41 @@ __host__ __device__ inline int stack_global_entries(int max_depth) {
 inline size_t stack_lds_bytes(int max_depth) {
     return (size_t)kWavesPerBlock * stack_lds_entries(max_depth) * kStackFields * 64 * sizeof(double);
 }
-// Bytes of global workspace one render needs: a region per wave of its grid.
-inline size_t stack_global_bytes(int max_depth, int tiles_x, int tiles_y) {
-    const size_t bx = (size_t)(tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
-    return bx * kWavesPerBlock * (size_t)tiles_y * stack_global_entries(max_depth) * kStackFields * 64 * sizeof(double);
+// Deep-stack launches: grid size and workspace.  The workspace starts with a 256-byte
+// header whose first word is the tile queue; the waves' regions follow.
+constexpr int kDeepMaxBlocks = 1024;      // 256 CUs x 4 resident blocks of 4 waves
+constexpr int kDeepBlocksPerCu = 4;
+constexpr size_t kWorkspaceHeader = 256;
+constexpr size_t kDeepRegionBytes =       // per wave, at RT_MAX_DEPTH
+    (size_t)(RT_MAX_DEPTH - 3 - kStackLdsEntries) * kStackFields * 64 * sizeof(double);
+constexpr size_t kWorkspaceMaxBytes = kWorkspaceHeader + (size_t)kDeepMaxBlocks * kWavesPerBlock * kDeepRegionBytes;
+inline int deep_grid_blocks(int n_cus, long long tiles) {
+    long long g = (long long)n_cus * kDeepBlocksPerCu;
+    if (g > kDeepMaxBlocks) g = kDeepMaxBlocks;
+    const long long need = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (g > need) g = need;
+    return (int)(g < 1 ? 1 : g);
+}
+// Bytes of workspace a deep launch of `blocks` blocks needs (0 when the depth needs none).
+inline size_t stack_workspace_bytes(int max_depth, int blocks) {
+    if (stack_global_entries(max_depth) == 0) return 0;
+    return kWorkspaceHeader + (size_t)blocks * kWavesPerBlock * kDeepRegionBytes;
 }
 
 // Arguments of up to kMaxBatch renders done by one launch (kernel argument segment: 4 KB).
 constexpr int kMaxBatch = 8;
 struct KBatch {
     KArgs a[kMaxBatch];
+    int32_t tile_end[kMaxBatch];   // deep-stack launches: running total of the renders' tiles
 };
 static_assert(sizeof(KBatch) <= 3072, "kernel argument segment");
-hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, hipStream_t stream);
+// deep_blocks: grid of a deep-stack launch (deep_grid_blocks), ignored otherwise.
+hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, int deep_blocks, hipStream_t stream);
 
 // Enqueue the render of one strip on `stream`.  emit = write hit_id/masks (pointers in
 // `a` that are null are skipped), count = add event counts to a.counters.
-hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, hipStream_t stream);
+// deep_blocks: grid of a deep-stack launch (deep_grid_blocks), ignored otherwise.
+hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, int deep_blocks, hipStream_t stream);
 
 
 // Enqueue the nearest-hit hook (rt_debug_nearest); only the scene fields of `a` are read.

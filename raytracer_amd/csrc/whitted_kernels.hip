@@ -26,65 +26,104 @@ __device__ __forceinline__ void flush_counters(const KArgs& a, const uint32_t (&
     }
 }
 
-// This wave's region of the global stack workspace (lane-major like the LDS part).
-// (tx, ty must be wave-uniform values: the result then stays in scalar registers.)
-__device__ __forceinline__ double* wave_gstack(const KArgs& a, int tx, int ty) {
-    const size_t waves_x = (size_t)((a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock) * kWavesPerBlock;
-    const size_t w = (size_t)ty * waves_x + tx;
-    return a.gstack + w * stack_global_entries(a.max_depth) * kStackFields * 64;
+// Region `w` (a wave of the launch) of the global stack workspace, lane-major like the LDS part.
+// (w must be a wave-uniform value: the result then stays in scalar registers.)
+__device__ __forceinline__ double* wave_gstack(const KArgs& a, size_t w) {
+    return a.gstack + w * (kDeepRegionBytes / sizeof(double));
 }
 
-// One wave per 8x8 pixel tile of the strip.
+// Deep-stack launches: the next tile of the queue, the same value in every lane.
+__device__ __forceinline__ int next_tile(unsigned int* queue, int lane) {
+    unsigned int t = 0;
+    if (lane == 0) t = atomicAdd(queue, 1u);
+    return (int)__builtin_amdgcn_readfirstlane(t);
+}
+
+// One wave per 8x8 pixel tile of the strip.  Without the deep stack the grid holds one wave
+// per tile; with it the grid is fixed and its waves take tiles from the queue.
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? 4 : 3, 4))) void whitted_kernel(KArgs a) {
     extern __shared__ double lds_stack[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* stk = lds_stack + (size_t)wave * stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
-    const int tx = blockIdx.x * kWavesPerBlock + wave;  // a block = 4 tiles side by side
-    const int ty = blockIdx.y;
-    const int x = tx * kTile + (lane & 7);
-    const int k = ty * kTile + (lane >> 3);  // row in strip order
-    const bool have = (x < a.width) && (k < a.rows);
-    double* gstk = wave_gstack(a, tx, ty);
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    trace_pixel<MW, COUNT, TREE, DEEP, LATE>(a, x, k, have, stk, gstk, lane, cnt);
+    if (DEEP) {
+        double* gstk = wave_gstack(a, (size_t)blockIdx.x * kWavesPerBlock + wave);
+        const int n_tiles = a.tiles_x * a.tiles_y;
+        for (int t = next_tile(a.tile_queue, lane); t < n_tiles; t = next_tile(a.tile_queue, lane)) {
+            const int ty = t / a.tiles_x;
+            const int tx = t - ty * a.tiles_x;
+            const int x = tx * kTile + (lane & 7);
+            const int k = ty * kTile + (lane >> 3);
+            trace_pixel<MW, COUNT, TREE, DEEP, LATE>(a, x, k, (x < a.width) && (k < a.rows), stk, gstk, lane, cnt);
+        }
+    } else {
+        const int tx = blockIdx.x * kWavesPerBlock + wave;  // a block = 4 tiles side by side
+        const int ty = blockIdx.y;
+        const int x = tx * kTile + (lane & 7);
+        const int k = ty * kTile + (lane >> 3);  // row in strip order
+        trace_pixel<MW, COUNT, TREE, DEEP, LATE>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
+    }
     flush_counters<COUNT>(a, cnt, lane);
 }
 
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
-static hipError_t launch_ttdl(const KArgs& a, hipStream_t stream) {
+static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t stream) {
     const int bx = (a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     if (bx <= 0 || a.tiles_y <= 0) return hipSuccess;
     const size_t lds = stack_lds_bytes(a.max_depth);
-    hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
+    if (DEEP) {
+        if (deep_blocks < 1 || deep_blocks > kDeepMaxBlocks || !a.tile_queue || !a.gstack) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE>), dim3(deep_blocks), dim3(64 * kWavesPerBlock), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
+    }
     return hipGetLastError();
 }
 
-// Several renders in one launch: blockIdx.z selects the render (its scene tables, camera,
-// partition and output), the arguments of all of them travel by value in the kernel
-// argument segment.  Image-only variant; the grid is sized for the largest render, blocks
-// outside a smaller one return at once.
+// Several renders in one launch; the arguments of all of them travel by value in the kernel
+// argument segment.  Image-only variant.  Without the deep stack blockIdx.z selects the
+// render, the grid is sized for the largest one and blocks outside a smaller one return at
+// once; with it the renders' tiles form one queue (tile_end = running totals).
 template <bool TREE, bool DEEP, bool LATE>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void whitted_batch_kernel(KBatch b) {
+void whitted_batch_kernel(KBatch b, int n) {
     extern __shared__ double lds_stack[];
-    const KArgs& a = b.a[blockIdx.z];
-    if ((int)blockIdx.y >= a.tiles_y || (int)(blockIdx.x * kWavesPerBlock) >= a.tiles_x) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* stk = lds_stack + (size_t)wave * stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
-    const int tx = blockIdx.x * kWavesPerBlock + wave;
-    const int ty = blockIdx.y;
-    const int x = tx * kTile + (lane & 7);
-    const int k = ty * kTile + (lane >> 3);
-    const bool have = (x < a.width) && (k < a.rows);
-    double* gstk = wave_gstack(a, tx, ty);
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    trace_pixel<0, false, TREE, DEEP, LATE>(a, x, k, have, stk, gstk, lane, cnt);
+    if (DEEP) {
+        // every render's stack entries sit at the offsets of the deepest render of the launch
+        int depth = 0;
+        for (int i = 0; i < n; ++i) depth = max(depth, b.a[i].max_depth);
+        double* stk = lds_stack + (size_t)wave * stack_lds_entries(depth) * kStackFields * 64 + lane;
+        double* gstk = wave_gstack(b.a[0], (size_t)blockIdx.x * kWavesPerBlock + wave);
+        const int n_tiles = b.tile_end[n - 1];
+        for (int t = next_tile(b.a[0].tile_queue, lane); t < n_tiles; t = next_tile(b.a[0].tile_queue, lane)) {
+            int r = 0;
+            while (t >= b.tile_end[r]) ++r;  // wave-uniform
+            const KArgs& a = b.a[r];
+            const int tr = t - (r ? b.tile_end[r - 1] : 0);
+            const int ty = tr / a.tiles_x;
+            const int tx = tr - ty * a.tiles_x;
+            const int x = tx * kTile + (lane & 7);
+            const int k = ty * kTile + (lane >> 3);
+            trace_pixel<0, false, TREE, DEEP, LATE>(a, x, k, (x < a.width) && (k < a.rows), stk, gstk, lane, cnt);
+        }
+    } else {
+        const KArgs& a = b.a[blockIdx.z];
+        if ((int)blockIdx.y >= a.tiles_y || (int)(blockIdx.x * kWavesPerBlock) >= a.tiles_x) return;
+        double* stk = lds_stack + (size_t)wave * stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
+        const int tx = blockIdx.x * kWavesPerBlock + wave;
+        const int ty = blockIdx.y;
+        const int x = tx * kTile + (lane & 7);
+        const int k = ty * kTile + (lane >> 3);
+        trace_pixel<0, false, TREE, DEEP, LATE>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
+    }
 }
 
-hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, hipStream_t stream) {
+hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, int deep_blocks, hipStream_t stream) {
     int bx = 0, by = 0, depth = 0;
     for (int i = 0; i < n; ++i) {
         const KArgs& a = b.a[i];
@@ -93,56 +132,57 @@ hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, hipStream_t s
         depth = max(depth, a.max_depth);
     }
     if (n <= 0 || bx <= 0 || by <= 0) return hipSuccess;
-    const dim3 grid(bx, by, n), block(64 * kWavesPerBlock);
     const size_t lds = stack_lds_bytes(depth);
     const bool deep = stack_global_entries(depth) > 0;
+    if (deep && (deep_blocks < 1 || deep_blocks > kDeepMaxBlocks || !b.a[0].tile_queue || !b.a[0].gstack))
+        return hipErrorInvalidValue;
+    const dim3 grid = deep ? dim3(deep_blocks) : dim3(bx, by, n);
+    const dim3 block(64 * kWavesPerBlock);
     bool late = !tree;  // every render of the batch must have many lights
     for (int i = 0; i < n; ++i) late = late && b.a[i].n_lights >= kLateMinLights;
-    if (tree && deep) hipLaunchKernelGGL((whitted_batch_kernel<true, true, false>), grid, block, lds, stream, b);
-    else if (tree) hipLaunchKernelGGL((whitted_batch_kernel<true, false, false>), grid, block, lds, stream, b);
-    else if (deep && late) hipLaunchKernelGGL((whitted_batch_kernel<false, true, true>), grid, block, lds, stream, b);
-    else if (deep) hipLaunchKernelGGL((whitted_batch_kernel<false, true, false>), grid, block, lds, stream, b);
-    else if (late) hipLaunchKernelGGL((whitted_batch_kernel<false, false, true>), grid, block, lds, stream, b);
-    else hipLaunchKernelGGL((whitted_batch_kernel<false, false, false>), grid, block, lds, stream, b);
+    if (tree && deep) hipLaunchKernelGGL((whitted_batch_kernel<true, true, false>), grid, block, lds, stream, b, n);
+    else if (tree) hipLaunchKernelGGL((whitted_batch_kernel<true, false, false>), grid, block, lds, stream, b, n);
+    else if (deep && late) hipLaunchKernelGGL((whitted_batch_kernel<false, true, true>), grid, block, lds, stream, b, n);
+    else if (deep) hipLaunchKernelGGL((whitted_batch_kernel<false, true, false>), grid, block, lds, stream, b, n);
+    else if (late) hipLaunchKernelGGL((whitted_batch_kernel<false, false, true>), grid, block, lds, stream, b, n);
+    else hipLaunchKernelGGL((whitted_batch_kernel<false, false, false>), grid, block, lds, stream, b, n);
     return hipGetLastError();
 }
 
 // The late-predicate shadow loop exists for the image-only kernel without the tree only.
 template <int MW, bool COUNT, bool TREE, bool DEEP>
-static hipError_t launch_ttd(const KArgs& a, hipStream_t stream) {
+static hipError_t launch_ttd(const KArgs& a, int deep_blocks, hipStream_t stream) {
     if (MW == 0 && !COUNT && !TREE && a.n_lights >= kLateMinLights)
-        return launch_ttdl<MW, COUNT, TREE, DEEP, (MW == 0 && !COUNT && !TREE)>(a, stream);
-    return launch_ttdl<MW, COUNT, TREE, DEEP, false>(a, stream);
+        return launch_ttdl<MW, COUNT, TREE, DEEP, (MW == 0 && !COUNT && !TREE)>(a, deep_blocks, stream);
+    return launch_ttdl<MW, COUNT, TREE, DEEP, false>(a, deep_blocks, stream);
 }
 
-// Only the image-only kernel exists without the deep-stack code; the others always carry it.
 template <int MW, bool COUNT, bool TREE>
-static hipError_t launch_tt(const KArgs& a, hipStream_t stream) {
-    if (MW == 0 && !COUNT && stack_global_entries(a.max_depth) == 0)
-        return launch_ttd<MW, COUNT, TREE, !(MW == 0 && !COUNT)>(a, stream);
-    return launch_ttd<MW, COUNT, TREE, true>(a, stream);
+static hipError_t launch_tt(const KArgs& a, int deep_blocks, hipStream_t stream) {
+    if (stack_global_entries(a.max_depth) == 0) return launch_ttd<MW, COUNT, TREE, false>(a, deep_blocks, stream);
+    return launch_ttd<MW, COUNT, TREE, true>(a, deep_blocks, stream);
 }
 
 template <int MW, bool COUNT>
-static hipError_t launch_t(const KArgs& a, bool tree, hipStream_t stream) {
-    return tree ? launch_tt<MW, COUNT, true>(a, stream) : launch_tt<MW, COUNT, false>(a, stream);
+static hipError_t launch_t(const KArgs& a, bool tree, int deep_blocks, hipStream_t stream) {
+    return tree ? launch_tt<MW, COUNT, true>(a, deep_blocks, stream) : launch_tt<MW, COUNT, false>(a, deep_blocks, stream);
 }
 
-hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, hipStream_t stream) {
+hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, int deep_blocks, hipStream_t stream) {
     const int mw = emit ? a.mask_words : 0;
     if (count) {
         switch (mw) {
-            case 0: return launch_t<0, true>(a, tree, stream);
-            case 1: return launch_t<1, true>(a, tree, stream);
-            case 2: return launch_t<2, true>(a, tree, stream);
-            case 4: return launch_t<4, true>(a, tree, stream);
+            case 0: return launch_t<0, true>(a, tree, deep_blocks, stream);
+            case 1: return launch_t<1, true>(a, tree, deep_blocks, stream);
+            case 2: return launch_t<2, true>(a, tree, deep_blocks, stream);
+            case 4: return launch_t<4, true>(a, tree, deep_blocks, stream);
         }
     } else {
         switch (mw) {
-            case 0: return launch_t<0, false>(a, tree, stream);
-            case 1: return launch_t<1, false>(a, tree, stream);
-            case 2: return launch_t<2, false>(a, tree, stream);
-            case 4: return launch_t<4, false>(a, tree, stream);
+            case 0: return launch_t<0, false>(a, tree, deep_blocks, stream);
+            case 1: return launch_t<1, false>(a, tree, deep_blocks, stream);
+            case 2: return launch_t<2, false>(a, tree, deep_blocks, stream);
+            case 4: return launch_t<4, false>(a, tree, deep_blocks, stream);
         }
     }
     return hipErrorInvalidValue;

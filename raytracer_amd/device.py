@@ -28,6 +28,10 @@ EXPORTS = (
     "rt_render",
     "rt_render_device",
     "rt_render_device_batch",
+    "rt_render_node",
+    "rt_trim",
+    "rt_host_alloc",
+    "rt_host_free",
     "rt_debug_intersect",
     "rt_debug_occluder",
     "rt_debug_nearest",
@@ -71,6 +75,10 @@ def load_library():
     L.rt_render.restype, L.rt_render.argtypes = ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp]
     L.rt_render_device.restype, L.rt_render_device.argtypes = ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]
     L.rt_render_device_batch.restype, L.rt_render_device_batch.argtypes = ctypes.c_int, [vp, vp, i32, vp, vp]
+    L.rt_render_node.restype, L.rt_render_node.argtypes = ctypes.c_int, [vp, i32, vp, i32, vp]
+    L.rt_trim.restype, L.rt_trim.argtypes = ctypes.c_int, [vp]
+    L.rt_host_alloc.restype, L.rt_host_alloc.argtypes = ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.rt_host_free.restype, L.rt_host_free.argtypes = None, [vp]
     L.rt_debug_nearest.restype = ctypes.c_int
     L.rt_debug_nearest.argtypes = [vp, vp, i32, ctypes.c_uint32, vp, vp]
     L.rt_debug_occluder.restype = ctypes.c_int
@@ -153,6 +161,19 @@ class DeviceTracer:
             )
         )
 
+    def render_into(self, params, out: np.ndarray):
+        """rt_render of the image alone into a caller's uint8 array (e.g. a HostFrame's)."""
+        p = np.array(params, dtype=abi.PARAMS_DTYPE)
+        rows = self._L.rt_strip_rows(_ptr(p))
+        if rows < 0 or out.dtype != np.uint8 or out.size != rows * int(p["width"]) * 3 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("render_into: `out` must be a contiguous uint8 array of rows*width*3 bytes")
+        self._check(self._L.rt_render(self._h, _ptr(p), _ptr(out), None, None, None, None))
+        return out
+
+    def trim(self):
+        """rt_trim: wait for the device and free the deep-stack workspaces."""
+        self._check(self._L.rt_trim(self._h))
+
     def debug_intersect(self, rays: np.ndarray, prim: int):
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
         n = len(rays)
@@ -201,3 +222,40 @@ class BatchPlan:
         )
         if rc != abi.RT_OK:
             raise RtError(rc, self._L.rt_last_error(self._tracers[0]._h).decode())
+
+
+class HostFrame:
+    """A page-locked host buffer (rt_host_alloc) viewed as a numpy uint8 array of `shape`."""
+
+    def __init__(self, shape):
+        self._L = load_library()
+        n = int(np.prod(shape))
+        p = ctypes.c_void_p()
+        rc = self._L.rt_host_alloc(max(n, 1), ctypes.byref(p))
+        if rc != abi.RT_OK:
+            raise RtError(rc, self._L.rt_last_error(None).decode())
+        self._p = p
+        self.array = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(max(n, 1),))[:n].reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._L.rt_host_free(self._p)
+            self._p = None
+
+    __del__ = close
+
+
+def render_node(tracers, params, out: np.ndarray, band_rows: int = 8):
+    """rt_render_node: one frame dealt out in bands of `band_rows` rows over `tracers` (each
+    holding the scene), written into `out` ([height, width, 3] uint8, host)."""
+    L = tracers[0]._L
+    p = np.array(params, dtype=abi.PARAMS_DTYPE)
+    h, w = int(p["height"]), int(p["width"])
+    if out.dtype != np.uint8 or out.size != h * w * 3 or not out.flags["C_CONTIGUOUS"]:
+        raise ValueError("render_node: `out` must be a contiguous uint8 array of height*width*3 bytes")
+    ctxs = (ctypes.c_void_p * len(tracers))(*[t._h for t in tracers])
+    rc = L.rt_render_node(ctxs, len(tracers), _ptr(p), band_rows, _ptr(out))
+    if rc != abi.RT_OK:
+        raise RtError(rc, L.rt_last_error(tracers[0]._h).decode())
+    return out

@@ -2,7 +2,7 @@
 // the reference's own construction calls, trace it on the GPU, write the frame to a file
 // and print the elapsed time.
 //   rt_main [--scene default|spheres1024|glass] [--orbit DEGREES] [--width W] [--height H]
-//           [--depth D] [--device N] [--out frame.bmp|frame.ppm]
+//           [--depth D] [--device N] [--frames N] [--out frame.bmp|frame.ppm]
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +17,7 @@ int main(int argc, char** argv) {
     std::string out = "frame.bmp";
     std::string scene = "default";
     double orbit_deg = 0.0;
+    int frames = 1;
     for (int i = 1; i < argc; ++i) {
         auto next = [&]() -> const char* {
             if (i + 1 >= argc) { std::cerr << "missing value after " << argv[i] << "\n"; std::exit(2); }
@@ -29,9 +30,10 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--out")) out = next();
         else if (!std::strcmp(argv[i], "--scene")) scene = next();
         else if (!std::strcmp(argv[i], "--orbit")) orbit_deg = std::atof(next());
+        else if (!std::strcmp(argv[i], "--frames")) frames = std::atoi(next());
         else {
             std::cerr << "usage: rt_main [--scene default|spheres1024|glass] [--orbit DEGREES] [--width W] "
-                         "[--height H] [--depth D] [--device N] [--out file]\n";
+                         "[--height H] [--depth D] [--device N] [--frames N] [--out file]\n";
             return 2;
         }
     }
@@ -49,15 +51,24 @@ int main(int argc, char** argv) {
     else { std::cerr << "unknown scene " << scene << "\n"; return 2; }
     if (orbit_deg != 0.0) OrbitScene(objs, lights, orbit_deg * 3.141592653589793 / 180.0);
 
+    const auto tr0 = std::chrono::high_resolution_clock::now();
     try {
         Tracer(bgr, *screen, objs, lights, opt);
+        for (int f = 1; f < frames; ++f) {  // more frames of the same scene: what a sequence pays per frame
+            screen->DrawScreen();
+            Tracer(bgr, *screen, objs, lights, opt);
+        }
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << "\n";
         return 1;
     }
+    const auto tr1 = std::chrono::high_resolution_clock::now();
     screen->DrawScreen();
 
     const auto t1 = std::chrono::high_resolution_clock::now();
+    std::cout << "Tracer: " << std::chrono::duration<double, std::milli>(tr1 - tr0).count() / 1000.0 << " Seconds ("
+              << frames << " call(s), first one with device set-up)\n";
     std::cout << "Time: " << std::chrono::duration<double, std::milli>(t1 - t0).count() / 1000.0 << " Seconds\n";
+    ReleaseTracerDevices();
     return 0;
 }

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <stdexcept>
 
 ViewFrustum::ViewFrustum(std::size_t scr_width, std::size_t scr_height, double angle, double view_plane_distance)
@@ -22,35 +23,101 @@ ViewFrustum::ViewFrustum(std::size_t scr_width, std::size_t scr_height, double a
 
 Screen::Screen(std::size_t width, std::size_t height, std::string output_path)
     : width_(width), height_(height), output_path_(std::move(output_path)) {
-    for (auto& b : buffers_) b.assign(width * height * 3, 0);
-    depth_.assign(width * height, 0);
+    const std::size_t bytes = width * height * 3;
+    void* a = nullptr;
+    void* b = nullptr;
+    if (bytes && rt_host_alloc(bytes, &a) == RT_OK && rt_host_alloc(bytes, &b) == RT_OK) {
+        page_locked_ = true;
+    } else {
+        if (a) rt_host_free(a);
+        a = new uint8_t[bytes ? bytes : 1];
+        b = new uint8_t[bytes ? bytes : 1];
+    }
+    buffers_[0] = static_cast<uint8_t*>(a);
+    buffers_[1] = static_cast<uint8_t*>(b);
+    std::memset(buffers_[0], 0, bytes);
+    std::memset(buffers_[1], 0, bytes);
+}
+
+Screen::~Screen() {
+    for (uint8_t* p : buffers_) {
+        if (page_locked_) rt_host_free(p);
+        else delete[] p;
+    }
+}
+
+void Screen::MaterialiseDepth() {
+    if (depth_.empty()) depth_.assign(width_ * height_, depth_floor_);
 }
 
 // The reference walks (row, column) but passes them to StorePixel as (x, y)
 // (src/screen.h:47-53), which only works for square frames; here x is the column.
 void Screen::ClearScreenColor(const Color& c) {
+    if (depth_.empty()) {
+        // every pixel at one depth: a store at depth 0 does nothing over a deeper frame and
+        // is the equal-depth merge over a frame at depth 0
+        if (depth_floor_ > 0) return;
+        uint8_t* back = buffers_[(front_ + 1) % 2];
+        const uint8_t v[3] = {c.blue(), c.green(), c.red()};
+        const std::size_t n = width_ * height_;
+        if (back_is_zero_) {
+            for (std::size_t i = 0; i < n; ++i) { back[3 * i] = v[0]; back[3 * i + 1] = v[1]; back[3 * i + 2] = v[2]; }
+        } else {
+            for (std::size_t i = 0; i < n; ++i)
+                for (int k = 0; k < 3; ++k) back[3 * i + k] = std::max(v[k], back[3 * i + k]);
+        }
+        back_is_zero_ = false;
+        return;
+    }
     for (std::size_t y = 0; y < height_; ++y)
         for (std::size_t x = 0; x < width_; ++x) StorePixel(x, y, 0, c);
 }
 
 // src/screen.h:55-73: nearer (larger z) wins, equal z keeps the brighter channel.
 void Screen::StorePixel(std::size_t x, std::size_t y, uint8_t z, const Color& c) {
-    std::vector<uint8_t>& back = buffers_[(front_ + 1) % 2];
+    MaterialiseDepth();
+    uint8_t* back = buffers_[(front_ + 1) % 2];
     const std::size_t px = y * width_ + x;
     uint8_t* dst = &back[3 * px];
     const uint8_t v[3] = {c.blue(), c.green(), c.red()};
     if (depth_[px] < z) {
         dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
         depth_[px] = z;
+        back_is_zero_ = false;
     } else if (depth_[px] == z) {
         for (int i = 0; i < 3; ++i) dst[i] = std::max(v[i], dst[i]);
+        back_is_zero_ = false;
     }
 }
 
+uint8_t* Screen::BeginFrameStore(uint8_t z) {
+    if (!depth_.empty()) return nullptr;
+    if (!(depth_floor_ < z || (depth_floor_ == z && back_is_zero_))) return nullptr;
+    depth_floor_ = z;
+    back_is_zero_ = false;
+    return buffers_[(front_ + 1) % 2];
+}
+
 void Screen::StoreRows(std::size_t first_row, std::size_t n_rows, uint8_t z, const uint8_t* bgr) {
-    std::vector<uint8_t>& back = buffers_[(front_ + 1) % 2];
+    uint8_t* back = buffers_[(front_ + 1) % 2];
+    if (first_row == 0 && n_rows == height_) {
+        if (uint8_t* dst = BeginFrameStore(z)) {
+            std::memcpy(dst, bgr, width_ * height_ * 3);
+            return;
+        }
+    }
+    MaterialiseDepth();
+    back_is_zero_ = false;
     for (std::size_t r = 0; r < n_rows; ++r) {
         const std::size_t y = first_row + r;
+        uint8_t* drow = &depth_[y * width_];
+        bool all_below = true;
+        for (std::size_t x = 0; x < width_ && all_below; ++x) all_below = drow[x] < z;
+        if (all_below) {  // the `<` branch for the whole row
+            std::memcpy(&back[3 * y * width_], bgr + 3 * r * width_, 3 * width_);
+            std::memset(drow, z, width_);
+            continue;
+        }
         for (std::size_t x = 0; x < width_; ++x) {
             const std::size_t px = y * width_ + x;
             const uint8_t* src = bgr + 3 * (r * width_ + x);
@@ -65,15 +132,16 @@ void Screen::StoreRows(std::size_t first_row, std::size_t n_rows, uint8_t z, con
 }
 
 // src/screen.h:81-99: clear the old front buffer, make the back buffer the front one,
-// present it.  Presenting = writing the file (the reference blits to the console).
+// present it.  Presenting = writing the file (the reference blits to the console).  The
+// depth buffer is left alone, as in the reference.
 void Screen::DrawScreen() {
-    std::fill(buffers_[front_].begin(), buffers_[front_].end(), 0);
+    std::memset(buffers_[front_], 0, width_ * height_ * 3);
     front_ = (front_ + 1) % 2;
-    std::fill(depth_.begin(), depth_.end(), 0);
+    back_is_zero_ = true;
     if (output_path_.empty()) return;
     const bool ppm = output_path_.size() > 4 && output_path_.compare(output_path_.size() - 4, 4, ".ppm") == 0;
-    if (ppm) WritePpm(output_path_, buffers_[front_].data(), width_, height_);
-    else WriteBmp(output_path_, buffers_[front_].data(), width_, height_);
+    if (ppm) WritePpm(output_path_, buffers_[front_], width_, height_);
+    else WriteBmp(output_path_, buffers_[front_], width_, height_);
 }
 
 namespace {
@@ -101,6 +169,10 @@ void WriteBmp(const std::string& path, const uint8_t* bgr, std::size_t width, st
     std::ofstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error("cannot open " + path);
     f.write(reinterpret_cast<const char*>(hdr), sizeof hdr);
+    if (pad == 0) {  // the frame is the file's pixel array as it stands
+        f.write(reinterpret_cast<const char*>(bgr), static_cast<std::streamsize>(3 * width * height));
+        return;
+    }
     const char zeros[4] = {0, 0, 0, 0};
     for (std::size_t y = 0; y < height; ++y) {
         f.write(reinterpret_cast<const char*>(bgr + 3 * width * y), static_cast<std::streamsize>(3 * width));
@@ -130,6 +202,29 @@ void Tracer(const Color& bgr, Screen& scr, const std::vector<std::unique_ptr<Obj
     Tracer(bgr, scr, objs, lights, TracerOptions{});
 }
 
+namespace {
+// One device context per device for the life of the process, with the scene it holds.
+struct DeviceSlot {
+    rt_ctx* ctx = nullptr;
+    std::vector<rt_prim> prims;
+    std::vector<rt_light> lights;
+    std::vector<uint8_t> staging;  // for frames that cannot go straight into the Screen
+};
+std::map<int, DeviceSlot>& device_slots() {
+    static std::map<int, DeviceSlot> slots;
+    return slots;
+}
+template <typename T>
+bool same_bytes(const std::vector<T>& a, const std::vector<T>& b) {
+    return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0);
+}
+}  // namespace
+
+void ReleaseTracerDevices() {
+    for (auto& kv : device_slots()) rt_destroy(kv.second.ctx);
+    device_slots().clear();
+}
+
 void Tracer(const Color& bgr, Screen& scr, const std::vector<std::unique_ptr<Object>>& objs,
             const std::vector<std::unique_ptr<PointLight>>& lights, const TracerOptions& opt) {
     // The view frustum of src/main.cc:126; the device recomputes the pixel pitch from the
@@ -143,16 +238,23 @@ void Tracer(const Color& bgr, Screen& scr, const std::vector<std::unique_ptr<Obj
     lts.reserve(lights.size());
     for (const auto& l : lights) lts.push_back(l->Flatten());
 
-    rt_ctx* ctx = nullptr;
-    if (rt_create(opt.device, &ctx) != RT_OK) throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
-    auto fail = [&](const char* what) {
-        std::string msg = std::string(what) + ": " + rt_last_error(ctx);
-        rt_destroy(ctx);
-        throw std::runtime_error(msg);
-    };
-    if (rt_upload_scene(ctx, prims.data(), static_cast<int32_t>(prims.size()), lts.data(),
-                        static_cast<int32_t>(lts.size())) != RT_OK)
-        fail("rt_upload_scene");
+    DeviceSlot& slot = device_slots()[opt.device];
+    if (!slot.ctx) {
+        if (rt_create(opt.device, &slot.ctx) != RT_OK) {
+            slot.ctx = nullptr;
+            throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
+        }
+    }
+    rt_ctx* ctx = slot.ctx;
+    auto fail = [&](const char* what) { throw std::runtime_error(std::string(what) + ": " + rt_last_error(ctx)); };
+    if (!same_bytes(prims, slot.prims) || !same_bytes(lts, slot.lights)) {
+        slot.prims.clear();
+        if (rt_upload_scene(ctx, prims.data(), static_cast<int32_t>(prims.size()), lts.data(),
+                            static_cast<int32_t>(lts.size())) != RT_OK)
+            fail("rt_upload_scene");
+        slot.prims = prims;
+        slot.lights = lts;
+    }
 
     rt_params p{};
     p.width = static_cast<int32_t>(vfr.Width());
@@ -165,8 +267,13 @@ void Tracer(const Color& bgr, Screen& scr, const std::vector<std::unique_ptr<Obj
     p.fov_deg = vfr.Angle();
     p.bgr[0] = bgr.r(); p.bgr[1] = bgr.g(); p.bgr[2] = bgr.b();
 
-    std::vector<uint8_t> frame(static_cast<std::size_t>(p.width) * p.height * 3);
-    if (rt_render(ctx, &p, frame.data(), nullptr, nullptr, nullptr, nullptr) != RT_OK) fail("rt_render");
-    rt_destroy(ctx);
-    scr.StoreRows(0, scr.Height(), 1, frame.data());  // StorePixel(x, y, 1, colour) for every pixel
+    // StorePixel(x, y, 1, colour) for every pixel: when that replaces the whole back buffer
+    // the device's frame is copied straight into it
+    if (uint8_t* dst = scr.BeginFrameStore(1)) {
+        if (rt_render(ctx, &p, dst, nullptr, nullptr, nullptr, nullptr) != RT_OK) fail("rt_render");
+        return;
+    }
+    slot.staging.resize(static_cast<std::size_t>(p.width) * p.height * 3);
+    if (rt_render(ctx, &p, slot.staging.data(), nullptr, nullptr, nullptr, nullptr) != RT_OK) fail("rt_render");
+    scr.StoreRows(0, scr.Height(), 1, slot.staging.data());
 }

@@ -176,27 +176,45 @@ private:
 };
 
 // Double-buffered 24-bit framebuffer, rows bottom-up, bytes B,G,R (the layout of the
-// reference's Screen).  DrawScreen() swaps and writes the front buffer to the output
-// path given at construction (".ppm" -> binary PPM, anything else -> BMP).
+// reference's Screen, src/screen.h:12-125).  DrawScreen() swaps and writes the front buffer
+// to the output path given at construction (".ppm" -> binary PPM, anything else -> BMP).
+// As in the reference the depth buffer is never reset: from the second frame on a store at
+// the same depth merges with a per-channel max into the (zeroed) back buffer, which gives the
+// same pixels as an overwrite.
+// The two pixel buffers are page-locked when the device library can provide such memory
+// (rt_host_alloc), so that a frame arrives in them at the full PCIe rate, and ordinary
+// memory otherwise.
 class Screen {
 public:
     Screen(std::size_t width, std::size_t height, std::string output_path = "");
+    ~Screen();
+    Screen(const Screen&) = delete;
+    Screen& operator=(const Screen&) = delete;
 
     void ClearScreenColor(const Color& c = {255, 255, 255});
     void StorePixel(std::size_t x, std::size_t y, uint8_t z, const Color& c = {255, 255, 255});
-    // Overwrite whole rows of the back buffer at depth z with already-quantised pixels
-    // (what the device returns); same visibility rule as StorePixel's `<` branch.
+    // StorePixel(x, y, z, colour) for whole rows of already-quantised pixels (what the
+    // device returns), same visibility rule, row-wise where a whole row passes the `<` test.
     void StoreRows(std::size_t first_row, std::size_t n_rows, uint8_t z, const uint8_t* bgr);
-    uint8_t* GetScreenData() { return buffers_[front_].data(); }
+    // When storing a whole frame at depth z would replace every pixel (every depth below z,
+    // or equal to z over a back buffer that is still all zero), mark the frame as stored and
+    // return the back buffer for the caller to fill directly; nullptr otherwise.
+    uint8_t* BeginFrameStore(uint8_t z);
+    uint8_t* GetScreenData() { return buffers_[front_]; }
     void DrawScreen();
     std::size_t Width() const { return width_; }
     std::size_t Height() const { return height_; }
+    bool PageLocked() const { return page_locked_; }
 
 private:
+    void MaterialiseDepth();
     std::size_t width_, height_;
     std::size_t front_ = 1;
-    std::array<std::vector<uint8_t>, 2> buffers_;
-    std::vector<uint8_t> depth_;
+    std::array<uint8_t*, 2> buffers_{{nullptr, nullptr}};
+    bool page_locked_ = false;
+    bool back_is_zero_ = true;          // nothing stored into the back buffer since it was cleared
+    uint8_t depth_floor_ = 0;           // depth of every pixel while depth_ is empty
+    std::vector<uint8_t> depth_;        // per-pixel depths once they stop being uniform
     std::string output_path_;
 };
 
@@ -208,11 +226,14 @@ struct TracerOptions {
 
 // Drop-in for the reference's Tracer() (src/main.cc:115-120): same arguments, same
 // effect on `scr` (every pixel stored at depth 1).  Throws std::runtime_error when the
-// device library reports an error.
+// device library reports an error.  The device context lives on between calls (one per
+// device and process) and the scene is only uploaded again when it has changed, so a
+// sequence of frames pays for set-up once; ReleaseTracerDevices() lets go of it.
 void Tracer(const Color& bgr, Screen& scr, const std::vector<std::unique_ptr<Object>>& objs,
             const std::vector<std::unique_ptr<PointLight>>& lights);
 void Tracer(const Color& bgr, Screen& scr, const std::vector<std::unique_ptr<Object>>& objs,
             const std::vector<std::unique_ptr<PointLight>>& lights, const TracerOptions& opt);
+void ReleaseTracerDevices();
 
 // Writers used by Screen::DrawScreen.
 void WriteBmp(const std::string& path, const uint8_t* bgr, std::size_t width, std::size_t height);

@@ -184,9 +184,9 @@ def test_deep_renders_on_two_streams(tracer):
 
 
 def test_render_device_under_graph_capture(tracer):
-    """rt_render_device / rt_render_device_batch enqueue one kernel and allocate nothing (for
-    depths up to 5; deeper renders after a first call on the stream), so they can be
-    captured in a HIP graph: four frames recorded once, replayed twice."""
+    """rt_render_device / rt_render_device_batch enqueue one kernel and allocate nothing at
+    depths up to 5, so they can be captured in a HIP graph: four frames recorded once,
+    replayed twice."""
     import torch
 
     from raytracer_amd.device import BatchPlan
@@ -257,3 +257,84 @@ def test_strip_exchange_over_rccl_single_rank(tracer):
         assert np.array_equal(g.frame(g.submit()).cpu().numpy(), want)
     finally:
         dist.destroy_process_group()
+
+
+def test_rt_render_in_parts_and_into_page_locked_memory(tracer):
+    """rt_render of the image alone renders the partition in parts and copies each part while
+    the next is rendered: whole frames, strips of bands and a clipped band, into ordinary
+    and into page-locked host memory, equal to the one-launch render with the id/mask outputs."""
+    from raytracer_amd.device import HostFrame
+
+    prims, lights = scenes.default_scene()
+    tracer.upload_scene(prims, lights)
+    cases = [abi.make_params(1920, 1083, 5), strips.rank_params(abi.make_params(1600, 1203, 4), 1, 3),
+             abi.make_params(1024, 700, 5, band_rows=300, band_first=1, band_step=1, band_count=1),
+             abi.make_params(1024, 700, 5, band_rows=400, band_first=0, band_step=1, band_count=1)]
+    for p in cases:
+        want = tracer.render(p)["bgr"]                      # one launch, not split
+        got = tracer.render(p, want_ids=False, want_masks=False)["bgr"]
+        assert np.array_equal(got, want)
+        hf = HostFrame(want.shape)
+        hf.array[:] = 3
+        tracer.render_into(p, hf.array)
+        assert np.array_equal(hf.array, want)
+        hf.close()
+    # a depth-8 frame in parts: every part's launch re-arms the tile queue of the workspace
+    tracer.upload_scene(*scenes.glass_scene())
+    p = abi.make_params(1280, 720, 8)
+    assert np.array_equal(tracer.render(p, want_ids=False, want_masks=False)["bgr"], tracer.render(p)["bgr"])
+    tracer.trim()
+    assert np.array_equal(tracer.render(p, want_ids=False, want_masks=False)["bgr"], tracer.render(p)["bgr"])
+
+
+@pytest.mark.parametrize("n_ctx,band_rows,size", [(1, 8, (640, 203)), (3, 8, (1920, 1083)), (8, 8, (3840, 2160)),
+                                                  (4, 16, (1000, 37)), (5, 8, (64, 20))])
+def test_render_node_equals_whole_frame(tracer, n_ctx, band_rows, size):
+    """rt_render_node: the frame dealt out in interleaved bands over n contexts (all on the one
+    GPU here, each with its own streams and staging), every part copied straight into its rows
+    of the caller's frame, equals the whole-frame render."""
+    from raytracer_amd.device import DeviceTracer, HostFrame, render_node
+
+    prims, lights = scenes.default_scene()
+    tracer.upload_scene(prims, lights)
+    others = [DeviceTracer(0) for _ in range(n_ctx - 1)]
+    for t in others:
+        t.upload_scene(prims, lights)
+    p = abi.make_params(size[0], size[1], 5)
+    want = tracer.render(p, want_ids=False, want_masks=False)["bgr"]
+    out = np.full(want.shape, 9, dtype=np.uint8)
+    render_node([tracer] + others, p, out, band_rows)
+    assert np.array_equal(out, want)
+    hf = HostFrame(want.shape)
+    hf.array[:] = 1
+    render_node([tracer] + others, p, hf.array, band_rows)
+    assert np.array_equal(hf.array, want)
+    hf.close()
+    for t in others:
+        t.close()
+
+
+def test_upload_rejects_what_the_filters_are_not_derived_for(tracer):
+    from raytracer_amd.device import RtError
+
+    prims, lights = scenes.default_scene()
+    bad = prims.copy()
+    bad[0]["q"] = (0.0, 2.0, 0.0)          # a plane normal that is not of unit length
+    with pytest.raises(RtError):
+        tracer.upload_scene(bad, lights)
+    bad = prims.copy()
+    bad[0]["q"] = (1000.0, -1000.0, 0.0)
+    with pytest.raises(RtError):
+        tracer.upload_scene(bad, lights)
+    bad = prims.copy()
+    bad[1]["reserved"] = 1
+    with pytest.raises(RtError):
+        tracer.upload_scene(bad, lights)
+    # the zero normal (what gmtl leaves of a zero vector) is a plane nothing ever hits
+    zero = prims.copy()
+    zero[0]["q"] = (0.0, 0.0, 0.0)
+    p = abi.make_params(64, 48, 4)
+    tracer.upload_scene(zero, lights)
+    dev = tracer.render(p, want_counters=True)
+    ora = oracle_lib.render(zero, lights, p, want_counters=True)
+    assert_parity(dev, ora, "zero normal")

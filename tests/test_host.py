@@ -44,6 +44,26 @@ int main(int argc, char** argv) {
     scr.DrawScreen();
     ViewFrustum v(640, 640, 60, 1000.0);
     printf("%.17g %.17g\n", v.PixelWidth(), v.PixelHeight());
+    // Two frames through the whole-frame store Tracer() uses.  As in the reference the depth
+    // buffer is never reset (src/screen.h:81-99): the second frame arrives at the depth the
+    // first one left, i.e. through the equal-depth merge, over a zeroed back buffer.
+    Screen two(4, 2, argv[3]);
+    two.ClearScreenColor(bgr);
+    std::vector<uint8_t> f1(4 * 2 * 3, 200), f2(4 * 2 * 3);
+    for (size_t i = 0; i < f2.size(); ++i) f2[i] = static_cast<uint8_t>(10 + i);
+    uint8_t* dst = two.BeginFrameStore(1);
+    if (!dst) return 3;                          // depth 0 everywhere: frame 1 overwrites
+    std::copy(f1.begin(), f1.end(), dst);
+    two.DrawScreen();
+    two.ClearScreenColor(bgr);                   // depth is 1 by now: a clear at depth 0 shows nothing
+    dst = two.BeginFrameStore(1);
+    if (!dst) return 4;                          // equal depth over a zeroed buffer: still a plain store
+    std::copy(f2.begin(), f2.end(), dst);
+    if (two.BeginFrameStore(1)) return 5;        // a second store at that depth must merge
+    std::vector<uint8_t> f3(4 * 2 * 3, 30);
+    two.StoreRows(0, 2, 1, f3.data());           // per-channel max with frame 2
+    two.StorePixel(0, 0, 2, Color{0.0, 0.0, 0.0});  // nearer: replaces
+    two.DrawScreen();
     return 0;
 }
 """
@@ -61,8 +81,8 @@ def test_cpp_scene_model_flattens_to_python_scene_bytes(tmp_path):
          "-Wl,-rpath," + os.path.join(ROOT, "raytracer_amd")],
         check=True,
     )
-    blob, bmp = tmp_path / "scene.bin", tmp_path / "s.bmp"
-    out = subprocess.run([str(exe), str(blob), str(bmp)], check=True, capture_output=True, text=True).stdout
+    blob, bmp, bmp2 = tmp_path / "scene.bin", tmp_path / "s.bmp", tmp_path / "two.bmp"
+    out = subprocess.run([str(exe), str(blob), str(bmp), str(bmp2)], check=True, capture_output=True, text=True).stdout
     raw = blob.read_bytes()
     prims = np.frombuffer(raw[: 4 * abi.PRIM_DTYPE.itemsize], dtype=abi.PRIM_DTYPE)
     lights = np.frombuffer(raw[4 * abi.PRIM_DTYPE.itemsize :], dtype=abi.LIGHT_DTYPE)
@@ -78,6 +98,11 @@ def test_cpp_scene_model_flattens_to_python_scene_bytes(tmp_path):
     assert (img[0, 0] == back).all()
     assert (img[2, 1] == [63, 229, 255]).all()  # B=max(.25,.1)*255, G=max(.5,.9)*255, R=max(1,.1)*255
     assert (img[0, 4] == [254, 0, 255]).all()  # clamped to [0,1], truncated
+    # the second of two frames: max(frame 2, 30) per channel, pixel (0,0) replaced at depth 2
+    two = frame.read_bmp(str(bmp2))
+    want = np.maximum(np.arange(10, 34, dtype=np.uint8).reshape(2, 4, 3), 30)
+    want[0, 0] = 0
+    assert np.array_equal(two, want)
     import math
 
     pw, ph = (float(v) for v in out.split())
