@@ -209,6 +209,23 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
                      rt_counters* d_counters);
 
 /*
+ * rt_render_device for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): same arguments, same
+ * results, but a render with max_depth > 5 keeps its stack workspace in an array built into
+ * the library (48 MiB + 256 bytes per GPU the library runs on, held until the process
+ * ends) instead of one allocated per stream, so the call never allocates or frees.  The
+ * array holds the stacks of the largest launch grid at max_depth 8, the library's limit;
+ * a larger max_depth is refused with RT_ERR_ARG like everywhere else, and the frame size
+ * does not matter.  All calls on one GPU share the array: two such renders with
+ * max_depth > 5 that overlap on one GPU (different streams or contexts) race; calls on one
+ * stream, or separated by a synchronisation, do not.  It has no counterpart in the
+ * reference.
+ */
+int rt_render_device_static(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_bgr,
+                            int32_t* d_hit_id, uint32_t* d_hit_mask, uint32_t* d_spawn_mask,
+                            rt_counters* d_counters);
+
+/*
  * n image-only renders on one device with ONE kernel launch, enqueued on `stream`: render i
  * uses the scene of ctxs[i] (contexts may repeat), params[i] (no RT_FLAG_COUNTERS; all
  * renders with or all without the sphere tree) and writes

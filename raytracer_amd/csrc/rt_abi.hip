@@ -53,6 +53,7 @@ struct rt_ctx {
     // rt_trim() frees them all.
     std::map<void*, void*> workspaces;
     size_t workspace_bytes = 0;
+    void* static_ws = nullptr;  // the library's built-in workspace on this device
     hipStream_t stream = nullptr;
     // rt_render / rt_render_node: second stream and events that let the copy of one part of
     // a frame run while the next part is rendered
@@ -241,6 +242,8 @@ int rt_create(int32_t device_id, rt_ctx** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copies_done, hipEventDisableTiming);
+    // the built-in workspace of rt_render_device_static: its address on THIS device
+    if (e == hipSuccess) e = rt::static_workspace(device_id, &ctx->static_ws);
     if (e != hipSuccess) {
         rt_destroy(ctx);
         return hip_fail(nullptr, e, "rt_create: device set-up");
@@ -476,7 +479,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
 }
 
 // Enqueue one render with device outputs on `stream`; the deep-stack workspace is `ws` when
-// given and this stream's own otherwise.  The caller has made the
+// given (the built-in one) and this stream's own otherwise.  The caller has made the
 // context's device current.
 static int enqueue_render(rt_ctx* ctx, const rt_params* p, hipStream_t stream, void* ws, uint8_t* d_bgr,
                           int32_t* d_hit_id, uint32_t* d_hit_mask, uint32_t* d_spawn_mask, rt_counters* d_counters) {
@@ -510,6 +513,23 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
     RT_HIP_TRY(ctx, guard.status);
     return enqueue_render(ctx, p, static_cast<hipStream_t>(stream), nullptr, d_bgr, d_hit_id, d_hit_mask, d_spawn_mask,
                           d_counters);
+}
+
+int rt_render_device_static(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_bgr, int32_t* d_hit_id,
+                            uint32_t* d_hit_mask, uint32_t* d_spawn_mask, rt_counters* d_counters) {
+    if (!ctx) return RT_ERR_ARG;
+    if (!d_bgr) return fail(ctx, RT_ERR_ARG, "rt_render_device_static: d_bgr is null");
+    if (!ctx->static_ws) return fail(ctx, RT_ERR_STATE, "rt_render_device_static: built-in workspace not available");
+    // the built-in workspace holds the stacks of kDeepMaxBlocks blocks at RT_MAX_DEPTH;
+    // a depth it has no room for is refused here (and by the parameter check for every
+    // entry point while RT_MAX_DEPTH is the library's limit)
+    if (p && rt::stack_global_entries(p->max_depth) * rt::kStackFields * 64 * sizeof(double) > rt::kDeepRegionBytes)
+        return fail(ctx, RT_ERR_ARG, "rt_render_device_static: max_depth needs more stack than the built-in "
+                                     "workspace holds (limit: max_depth 8)");
+    DeviceGuard guard(ctx->device);
+    RT_HIP_TRY(ctx, guard.status);
+    return enqueue_render(ctx, p, static_cast<hipStream_t>(stream), ctx->static_ws, d_bgr, d_hit_id, d_hit_mask,
+                          d_spawn_mask, d_counters);
 }
 
 int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t n, void* stream,

@@ -145,6 +145,10 @@ static_assert(sizeof(KBatch) <= 3072, "kernel argument segment");
 // deep_blocks: grid of a deep-stack launch (deep_grid_blocks), ignored otherwise.
 hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, int deep_blocks, hipStream_t stream);
 
+// The library's built-in workspace (a file-scope device array of kWorkspaceMaxBytes): its
+// address on the CURRENT device, looked up once per device.
+hipError_t static_workspace(int device, void** ptr);
+
 // Enqueue the render of one strip on `stream`.  emit = write hit_id/masks (pointers in
 // `a` that are null are skipped), count = add event counts to a.counters.
 // deep_blocks: grid of a deep-stack launch (deep_grid_blocks), ignored otherwise.

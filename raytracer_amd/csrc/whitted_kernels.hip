@@ -26,6 +26,29 @@ __device__ __forceinline__ void flush_counters(const KArgs& a, const uint32_t (&
     }
 }
 
+// The library's own workspace for deep-stack launches made through the entry point that
+// must not allocate (rt_render_device_static): tile queue + one stack region per wave of the
+// largest deep grid.  Each GPU the library runs on holds its own copy until the process
+// ends.  Host code never uses the array's name as an address: static_workspace() asks the
+// runtime for the device address, once per device.
+static __device__ __align__(256) unsigned char scratch[kWorkspaceMaxBytes];
+
+constexpr int kMaxDevices = 64;
+static void* g_scratch_ptr[kMaxDevices];
+
+hipError_t static_workspace(int device, void** ptr) {
+    *ptr = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));  // of the current device
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = p;
+    }
+    *ptr = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 // Region `w` (a wave of the launch) of the global stack workspace, lane-major like the LDS part.
 // (w must be a wave-uniform value: the result then stays in scalar registers.)
 __device__ __forceinline__ double* wave_gstack(const KArgs& a, size_t w) {

@@ -27,6 +27,7 @@ EXPORTS = (
     "rt_upload_scene",
     "rt_render",
     "rt_render_device",
+    "rt_render_device_static",
     "rt_render_device_batch",
     "rt_render_node",
     "rt_trim",
@@ -74,6 +75,8 @@ def load_library():
     L.rt_upload_scene.restype, L.rt_upload_scene.argtypes = ctypes.c_int, [vp, vp, i32, vp, i32]
     L.rt_render.restype, L.rt_render.argtypes = ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp]
     L.rt_render_device.restype, L.rt_render_device.argtypes = ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rt_render_device_static.restype = ctypes.c_int
+    L.rt_render_device_static.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.rt_render_device_batch.restype, L.rt_render_device_batch.argtypes = ctypes.c_int, [vp, vp, i32, vp, vp]
     L.rt_render_node.restype, L.rt_render_node.argtypes = ctypes.c_int, [vp, i32, vp, i32, vp]
     L.rt_trim.restype, L.rt_trim.argtypes = ctypes.c_int, [vp]
@@ -156,6 +159,19 @@ class DeviceTracer:
         as_vp = lambda v: ctypes.c_void_p(v) if v else None
         self._check(
             self._L.rt_render_device(
+                self._h, _ptr(p), as_vp(stream), as_vp(d_bgr), as_vp(d_hit_id), as_vp(d_hit_mask),
+                as_vp(d_spawn_mask), as_vp(d_counters),
+            )
+        )
+
+    def render_device_static(self, params, stream: int, d_bgr: int, d_hit_id: int = 0, d_hit_mask: int = 0,
+                             d_spawn_mask: int = 0, d_counters: int = 0):
+        """rt_render_device_static: as render_device, but a deep-stack render uses the
+        workspace built into the library, so the call never allocates."""
+        p = np.array(params, dtype=abi.PARAMS_DTYPE)
+        as_vp = lambda v: ctypes.c_void_p(v) if v else None
+        self._check(
+            self._L.rt_render_device_static(
                 self._h, _ptr(p), as_vp(stream), as_vp(d_bgr), as_vp(d_hit_id), as_vp(d_hit_mask),
                 as_vp(d_spawn_mask), as_vp(d_counters),
             )
