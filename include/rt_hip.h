@@ -146,7 +146,7 @@ void rt_destroy(rt_ctx* ctx);
 /*
  * Device memory a context holds besides the scene and the staging buffers of rt_render
  * (which grow to the largest frame rendered): renders with max_depth > 5 keep part of their
- * ray stacks in a workspace of 48 MiB (256 CUs), one per stream such a render was enqueued
+ * ray stacks in a workspace of 42 MiB (256 CUs), one per stream such a render was enqueued
  * on, allocated at the first such render on that stream.  rt_trim() waits for the device to
  * go idle and frees these workspaces (a later render allocates afresh); a caller that
  * creates streams freely calls it now and then.  No counterpart in the reference.
@@ -212,7 +212,7 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
  * rt_render_device for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc): same arguments, same
  * results, but a render with max_depth > 5 keeps its stack workspace in an array built into
- * the library (48 MiB + 256 bytes per GPU the library runs on, held until the process
+ * the library (42 MiB + 256 bytes per GPU the library runs on, held until the process
  * ends) instead of one allocated per stream, so the call never allocates or frees.  The
  * array holds the stacks of the largest launch grid at max_depth 8, the library's limit;
  * a larger max_depth is refused with RT_ERR_ARG like everywhere else, and the frame size
@@ -285,7 +285,8 @@ int rt_debug_nearest(rt_ctx* ctx, const double* rays, int32_t n, uint32_t flags,
  *   self        index of the object that is skipped (the shaded one), -1 = none
  *   flags       RT_FLAG_LINEAR / RT_FLAG_TREE as in rt_params.flags, 0 = by scene size
  *   first_out   n int32: index of the first occluder in container order, -1 = none
- *   factor_out  n doubles: its transmission factor (src/objects.h:40-46), 1.0 when none
+ *   factor_out  n doubles: its transmission factor (src/objects.h:40-46), 1.0 when none;
+ *               colour arithmetic, evaluated in single precision on the device
  */
 int rt_debug_occluder(rt_ctx* ctx, const double* points, int32_t n, int32_t light, int32_t self,
                       uint32_t flags, int32_t* first_out, double* factor_out);

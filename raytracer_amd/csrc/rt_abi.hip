@@ -188,8 +188,17 @@ int make_args(rt_ctx* ctx, const rt_params* p, rt::KArgs& a) {
     const double phy_height = aspect * phy_width;
     a.pw = phy_width / p->width;
     a.ph = phy_height / p->height;
-    for (int i = 0; i < 3; ++i) a.bgr_c[i] = p->bgr[i];
-    for (int dpt = 1; dpt <= RT_MAX_DEPTH; ++dpt) a.inv_depth[dpt] = 1.0 / dpt;  // src/main.cc:112
+    for (int i = 0; i < 3; ++i) a.bgr_c[i] = static_cast<float>(p->bgr[i]);
+    for (int dpt = 1; dpt <= RT_MAX_DEPTH; ++dpt) a.inv_depth[dpt] = static_cast<float>(1.0 / dpt);  // src/main.cc:112
+    // row k of the strip lies in band k / band_rows: exact as a multiply-high for k < 2^16
+    // (frames are at most 65536 rows; a band of 65536 rows holds them all)
+    a.band_magic = (p->band_rows >= 65536) ? 0u : static_cast<uint32_t>(((1ull << 32) + p->band_rows - 1) / p->band_rows);
+    if (p->band_rows == 1) a.band_magic = 0xffffffffu;  // unused: band = k
+    // the primary ray's p1 = ((xi + .5) pw, (yi + .5) ph, 1): inside the range in which the
+    // short normalisation is exact when the smallest and largest components are
+    const double cmin = 0.5 * (a.pw < a.ph ? a.pw : a.ph);
+    const double cmax = (0.5 * p->width + 1.0) * a.pw + (0.5 * p->height + 1.0) * a.ph;
+    a.primary_in_range = (cmin >= 0x1p-370 && cmax <= 0x1p370) ? 1 : 0;
     return RT_OK;
 }
 
@@ -326,7 +335,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         for (int c = 0; c < 3; ++c) {
             g.p[c] = s.p[c];
             g.q[c] = s.q[c];
-            m.kd[c] = s.kd[c];
+            m.kd[c] = static_cast<float>(s.kd[c]);
         }
         // std::pow(radius_, 2) (src/objects.h:125) is radius_*radius_ correctly rounded.
         g.r2 = (s.type == RT_PRIM_PLANE) ? -1.0 : s.q[0] * s.q[0];
@@ -345,12 +354,12 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
                 return fail(ctx, RT_ERR_ARG, "rt_upload_scene: plane normal is not of unit length (pass normal_ as "
                                              "stored by the Plane constructor)");
         }
-        g.transparency = s.transparency;
-        m.reflectivity = s.reflectivity;
-        m.transparency = s.transparency;
+        g.transparency = static_cast<float>(s.transparency);
+        m.reflectivity = static_cast<float>(s.reflectivity);
+        m.transparency = static_cast<float>(s.transparency);
         m.refraction_index = s.refraction_index;
-        m.ambient_intensity = s.ambient_intensity;
-        m.pad = 1.0 / s.refraction_index;  // src/main.cc:64, the same division done once
+        m.ambient_intensity = static_cast<float>(s.ambient_intensity);
+        m.inv_refraction_index = 1.0 / s.refraction_index;  // src/main.cc:64, the same division done once
     }
     for (int i = 0; i < n_lights; ++i) {
         for (int c = 0; c < 3; ++c)
@@ -359,7 +368,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         std::memset(&lt[i], 0, sizeof lt[i]);
         for (int c = 0; c < 3; ++c) {
             lt[i].pos[c] = lights[i].pos[c];
-            lt[i].ci[c] = lights[i].color[c] * lights[i].intensity;  // src/objects.h:54-56
+            lt[i].ci[c] = static_cast<float>(lights[i].color[c] * lights[i].intensity);  // src/objects.h:54-56
         }
     }
     // float image of the geometry with the rounding error of each record (U = 2^-24

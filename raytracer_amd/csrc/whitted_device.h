@@ -20,24 +20,29 @@ struct DGeom {
     double p[3];
     double q[3];
     double r2;
-    double transparency;
+    float transparency;  // colour only: what an occluder lets through (src/objects.h:44)
+    float pad;
 };
 
-// Material of one collider, gathered per lane once per hit.
+// Material of one collider, gathered per lane once per hit.  The refraction index decides
+// whether a refraction ray exists (src/main.cc:86-87) and stays double; everything that only
+// scales colours is single precision.
 struct DMat {
-    double kd[3];
-    double reflectivity;
-    double transparency;
     double refraction_index;
-    double ambient_intensity;
-    double pad;  // 1.0 / refraction_index
+    double inv_refraction_index;  // 1.0 / refraction_index (src/main.cc:64)
+    float kd[3];
+    float reflectivity;
+    float transparency;
+    float ambient_intensity;
+    float pad[6];
 };
 
-// One point light; ci = light_color * double(intensity) (src/objects.h:54-56).
+// One point light; ci = light_color * double(intensity) (src/objects.h:54-56), rounded to
+// single precision (colour only).
 struct DLight {
     double pos[3];
-    double ci[3];
-    double pad[2];
+    float ci[3];
+    float pad[7];
 };
 
 static_assert(sizeof(DGeom) == 64 && sizeof(DMat) == 64 && sizeof(DLight) == 64, "record size");
@@ -54,8 +59,9 @@ struct FGeom {
 };
 static_assert(sizeof(FGeom) == 32, "record size");
 
-// Per-lane stack entry in LDS: origin xyz, direction xyz, weight, node number.
-constexpr int kStackFields = 8;
+// Per-lane stack entry: origin xyz, direction xyz, and one field that holds the path weight
+// (float) and the node number.
+constexpr int kStackFields = 7;
 constexpr int kWavesPerBlock = 4;
 constexpr int kTile = 8;  // a wave renders an 8x8 pixel tile
 
@@ -87,19 +93,21 @@ struct KArgs {
     int32_t tiles_x, tiles_y;  // 8x8 tiles covering width x rows
     int32_t mask_words;
     double pw, ph;             // pixel pitch (src/view_frustum.h:33-34)
-    double bgr_c[3];
-    double inv_depth[RT_MAX_DEPTH + 1];  // 1.0/depth for depth 1..max_depth-1
+    float bgr_c[3];            // background colour
+    float inv_depth[RT_MAX_DEPTH + 1];  // 1.0/depth for depth 1..max_depth-1
     float scene_p1max;         // >= |centre|_1 of every sphere (filter bound)
+    uint32_t band_magic;       // ceil(2^32 / band_rows): k / band_rows = mulhi(k, band_magic), k < 2^16
+    int32_t primary_in_range;  // every primary ray's p1 passes the range guard of unit()
 };
 
-// The walk keeps at most one pending refraction child per tree level 2..max_depth-1, 4 KB
+// The walk keeps at most one pending refraction child per tree level 2..max_depth-1, 3.5 KB
 // per wave and entry.  Entry 0 (pushed by the primary hit) lives in registers, the next
-// kStackLdsEntries in LDS (what bounds the number of resident waves: 8 KB per wave keeps
+// kStackLdsEntries in LDS (what bounds the number of resident waves: 7 KB per wave keeps
 // four waves per SIMD), deeper ones in a global-memory workspace, written and read back by
 // the same wave while it is still in the L2.  A launch that needs the workspace (max_depth
 // > 5) is a fixed grid of at most kDeepMaxBlocks blocks whose waves take 8x8 tiles from a
 // queue (one atomic add per tile) until it is empty, so the workspace holds one region per
-// wave of that grid whatever the frame size: 48 MiB for the full grid at max_depth 8.
+// wave of that grid whatever the frame size: 42 MiB for the full grid at max_depth 8.
 constexpr int kStackLdsEntries = 2;
 __host__ __device__ inline int stack_entries(int max_depth) { return max_depth > 2 ? max_depth - 2 : 0; }
 __host__ __device__ inline int stack_lds_entries(int max_depth) {

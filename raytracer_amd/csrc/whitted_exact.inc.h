@@ -28,6 +28,29 @@
 // Everything below must be compiled without multiply-add contraction.
 #pragma clang fp contract(off)
 
+// Analysis builds only (tools/phase_budget.py): RT_PHASE_MARKERS puts a comment line into
+// the assembly wherever a phase of the per-pixel walk begins, so that the static
+// instructions of the kernel can be attributed to phases; RT_PHASE_PROFILE also makes the
+// counting kernels count how often a wave enters each of eight phases (in place of the event
+// counters).  Neither is defined in the library that ships.
+#if defined(RT_PHASE_PROFILE) && !defined(RT_PHASE_MARKERS)
+#define RT_PHASE_MARKERS 1
+#endif
+#ifdef RT_PHASE_MARKERS
+#define RT_MARK(name) __asm__ volatile("; RT_PHASE " name ::: "memory")
+#else
+#define RT_MARK(name) ((void)0)
+#endif
+#ifdef RT_PHASE_PROFILE
+#define RT_ENTER(counter)                                                                              \
+    do {                                                                                               \
+        const int me__ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      \
+        if (__builtin_amdgcn_readfirstlane(me__) == me__) ++(counter);                                 \
+    } while (0)
+#else
+#define RT_ENTER(counter) ((void)0)
+#endif
+
 namespace rt {
 namespace exact {
 
@@ -44,15 +67,20 @@ __device__ __forceinline__ DGeom load_geom(cdata_t t, int i) {
     g.p[0] = r[0]; g.p[1] = r[1]; g.p[2] = r[2];
     g.q[0] = r[3]; g.q[1] = r[4]; g.q[2] = r[5];
     g.r2 = r[6];
-    g.transparency = r[7];
+    g.transparency = ((const RT_CONST float*)(r + 7))[0];
+    g.pad = 0.0f;
     return g;
 }
-__device__ __forceinline__ DLight load_light(cdata_t t, int i) {
+struct LightRec {       // one DLight in scalar registers
+    double pos[3];
+    float ci[3];
+};
+__device__ __forceinline__ LightRec load_light(cdata_t t, int i) {
     const cdata_t r = t + (size_t)i * 8;
-    DLight l;
+    const RT_CONST float* f = (const RT_CONST float*)(r + 3);
+    LightRec l;
     l.pos[0] = r[0]; l.pos[1] = r[1]; l.pos[2] = r[2];
-    l.ci[0] = r[3]; l.ci[1] = r[4]; l.ci[2] = r[5];
-    l.pad[0] = 0.0; l.pad[1] = 0.0;
+    l.ci[0] = f[0]; l.ci[1] = f[1]; l.ci[2] = f[2];
     return l;
 }
 
@@ -142,8 +170,16 @@ __device__ __forceinline__ V3 unit_mid(V3 a, double l2) {
 }
 __device__ __forceinline__ V3 unit(V3 a) {
     const double l2 = len2(a);
-    if (all_lanes((l2 >= 0x1p-760) & (l2 <= 0x1p760) & mid_vec(a, 0x1p-380))) return unit_mid(a, l2);
-    return unit_plain(a);
+    V3 r;
+    if (all_lanes((l2 >= 0x1p-760) & (l2 <= 0x1p760) & mid_vec(a, 0x1p-380))) {
+        RT_MARK("resume");
+        r = unit_mid(a, l2);
+    } else {
+        RT_MARK("fallback");
+        r = unit_plain(a);
+    }
+    RT_MARK("resume");
+    return r;
 }
 // unit(unit(a)): a Ray's constructor normalises the direction it is given, which the
 // caller has normalised already (src/common.h:24).  One guard covers both passes: with
@@ -151,54 +187,67 @@ __device__ __forceinline__ V3 unit(V3 a) {
 // zero or >= 2^-500 and a squared length within a few 2^-52 of 1.
 __device__ __forceinline__ V3 unit2(V3 a) {
     const double l2 = len2(a);
+    V3 r;
     if (all_lanes((l2 >= 0x1p-500) & (l2 <= 0x1p500) & mid_vec(a, 0x1p-250))) {
+        RT_MARK("resume");
         const V3 u = unit_mid(a, l2);
-        return unit_mid(u, len2(u));
+        r = unit_mid(u, len2(u));
+    } else {
+        RT_MARK("fallback");
+        r = unit_plain(unit_plain(a));
     }
-    return unit_plain(unit_plain(a));
+    RT_MARK("resume");
+    return r;
 }
 
 // a / s, component by component, for |a_i| <= 2 max(s, 1) (both callers guarantee it).
 __device__ __forceinline__ V3 div3(V3 a, double s) {
+    V3 r;
     if (all_lanes((s >= 0x1p-380) & (s <= 0x1p380) & mid_vec(a, 0x1p-380))) {
+        RT_MARK("resume");
         const double y = rcp_refined(s);
-        return mk(div_mid(a.x, s, y), div_mid(a.y, s, y), div_mid(a.z, s, y));
+        r = mk(div_mid(a.x, s, y), div_mid(a.y, s, y), div_mid(a.z, s, y));
+    } else {
+        RT_MARK("fallback");
+        r = mk(a.x / s, a.y / s, a.z / s);
     }
-    return mk(a.x / s, a.y / s, a.z / s);
+    RT_MARK("resume");
+    return r;
 }
 // 1.0 / sqrt(x), both operations correctly rounded (src/main.cc:88).
 __device__ __forceinline__ double inv_sqrt_2r(double x) {
+    double r;
     if (all_lanes((x >= 0x1p-760) & (x <= 0x1p760))) {
+        RT_MARK("resume");
         const double sx = sqrt_mid(x);
         const double y = rcp_refined(sx);
-        return __builtin_fma(__builtin_fma(-sx, y, 1.0), y, y);
+        r = __builtin_fma(__builtin_fma(-sx, y, 1.0), y, y);
+    } else {
+        RT_MARK("fallback");
+        r = 1.0 / __builtin_sqrt(x);
     }
-    return 1.0 / __builtin_sqrt(x);
+    RT_MARK("resume");
+    return r;
 }
 
-// x*x*x with one rounding (the reference calls std::pow(x, 3), src/main.cc:101, which
-// the C library evaluates to within a rounding of the exact cube).
-__device__ __forceinline__ double cube_rn(double x) {
-    double p = x * x;
-    double pe = __builtin_fma(x, x, -p);
-    double q = p * x;
-    double qe = __builtin_fma(p, x, -q);
-    return q + (qe + pe * x);
+// ---- colour arithmetic ------------------------------------------------------------------
+// Nothing computed from a colour ever decides a hit, a miss or a spawn, so the colour chain
+// (shading terms, Fresnel weights, path weights, accumulation) runs in single precision with
+// fused multiply-adds.  Against the reference's double chain a channel moves by a few 1e-7
+// of its value, i.e. the 8-bit value differs (by one) only where the double colour times 255
+// sits within ~1e-4 of an integer: a few pixels in ten thousand.
+
+// src/color.h:77-79 with amount = 0.1f: b*amount + a*(1-amount) (the reference rounds the
+// double expression to float; here it is evaluated in float).
+__device__ __forceinline__ float mix_tenth(float a, float b) {
+    return __builtin_fmaf(a, 1.0f - 0.1f, b * 0.1f);
 }
 
-// src/color.h:77-79 with amount = 0.1f: the double expression rounded to float.
-__device__ __forceinline__ double mix_tenth(double a, double b) {
-    const double amount = (double)0.1f;
-    float r = (float)((b * amount) + a * (1 - amount));
-    return (double)r;
-}
-
-// src/color.h:27-29; a NaN channel is defined as 0.
-__device__ __forceinline__ uint32_t to_u8(double v) {
-    double c = (v < 0.0) ? 0.0 : ((1.0 < v) ? 1.0 : v);
-    double s = c * 255;
-    if (!(s == s)) return 0;
-    return (uint32_t)(int)s;
+// src/color.h:27-29: uint8_t(clamp(v,0,1)*255), truncating; a NaN channel is defined as 0
+// (v_med3_f32 returns the smallest operand for a NaN input).
+__device__ __forceinline__ uint32_t to_u8(float v) {
+    const float c = __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f);
+    return (uint32_t)(int)(c * 255.0f);
 }
 
 
@@ -376,14 +425,23 @@ __device__ __forceinline__ double collision_value(double pa, double pb) {
     const double ts = (t0 < 0) ? pa + thc : t0;
     return (pb < 0) ? pa : ts;
 }
-// Transmission factor of the occluder `og` of the feeler (ip, fdir), src/objects.h:40-46.
-__device__ __forceinline__ double occluder_factor(const DGeom* og, V3 ip, V3 fdir, double pa, double pb) {
+// Transmission factor of an occluder (src/objects.h:40-46), colour arithmetic: `m` = its
+// normal before normalisation (a plane's stored normal, or hit point - centre), fd = the
+// feeler's direction.
+__device__ __forceinline__ float transmission(V3 m, V3 fd, float transparency) {
+    const float mx = (float)m.x, my = (float)m.y, mz = (float)m.z;
+    const float md = __builtin_fmaf(mz, (float)fd.z, __builtin_fmaf(my, (float)fd.y, mx * (float)fd.x));
+    const float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx)));
+    const float facing = -(md * inv);
+    const float fres = mix_tenth(1.0f - facing, 0.0f);
+    return (1.0f - fres) * transparency;
+}
+// The same for the occluder `og` the tree walk found for the feeler (ip, fdir).
+__device__ __forceinline__ float occluder_factor(const DGeom* og, V3 ip, V3 fdir, double pa, double pb) {
     const double p = collision_value(pa, pb);
     const V3 hp = ip + fdir * p;
-    const V3 no = unit((pb < 0) ? mk(og->q[0], og->q[1], og->q[2]) : (hp - mk(og->p[0], og->p[1], og->p[2])));
-    const double facing = -dot(no, fdir);
-    const double fres = mix_tenth(1 - facing, 0.0);
-    return (1 - fres) * og->transparency;
+    const V3 m = (pb < 0) ? mk(og->q[0], og->q[1], og->q[2]) : (hp - mk(og->p[0], og->p[1], og->p[2]));
+    return transmission(m, fdir, og->transparency);
 }
 
 // ---- sphere tree (large scenes) -------------------------------------------------------
@@ -450,7 +508,9 @@ template <bool COUNT>
 __device__ __forceinline__ void find_nearest_tree(const KArgs& a, cdata_t geom, V3 o, V3 d, double& nearest, int& cur,
                                                   uint32_t& c_sph, uint32_t& c_pln) {
     const FilterRay fr = filter_ray(o, d, a.scene_p1max);
+#ifndef RT_PHASE_PROFILE
     if (COUNT) { c_sph += (uint32_t)(a.n_prims - a.n_planes); c_pln += (uint32_t)a.n_planes; }
+#endif
     cfdata_t pp = (cfdata_t)(const float*)a.planes;
     for (int k = 0; k < a.n_planes; ++k, pp += 8) {
         const FRec gf = load_rec(pp);
@@ -525,16 +585,21 @@ __device__ __forceinline__ FGroup load_group(cfdata_t fp) {
 template <bool COUNT>
 __device__ __forceinline__ void near_slot(const FRec& gf, cdata_t gp, int j, int idx, bool valid, const FilterRay& fr,
                                           V3 o, V3 d, double& nearest, int& cur, uint32_t& c_sph, uint32_t& c_pln) {
+#ifndef RT_PHASE_PROFILE
     if (COUNT && valid) { if (__float_as_int(gf.r2) < 0) ++c_pln; else ++c_sph; }
+#endif
     const bool maybe = valid && !certain_miss(gf, fr);
     if (maybe) {
         __asm__ volatile("" ::: "memory");  // nothing of the double test is to run ahead of the branch
+        RT_MARK("near_exact");
+        RT_ENTER(c_sph);
         const DGeom g = load_geom(gp, j);
         double t;
         const bool closer = test_collision(g, o, d, t) && t < nearest;
         nearest = closer ? t : nearest;
         cur = closer ? idx : cur;
     }
+    RT_MARK("near_filter");
 }
 
 // Slot of a shadow feeler's loop (src/objects.h:31-47): the first occluder in container
@@ -542,29 +607,32 @@ __device__ __forceinline__ void near_slot(const FRec& gf, cdata_t gp, int j, int
 // `factor` = its transmission factor.
 template <bool COUNT, bool LATE>
 __device__ __forceinline__ void feeler_slot(const LRec& lr, cfdata_t fp, cdata_t gp, int j, int idx, bool valid,
-                                            const FilterRay& fr, V3 ip, V3 fdir, int cur, int& first, double& factor,
+                                            const FilterRay& fr, V3 ip, V3 fdir, int cur, int& first, float& factor,
                                             uint32_t& c_sph, uint32_t& c_pln) {
     // Whether the reference makes this test at all (no occluder met yet, not the shaded
     // object) can be asked before the line test or, LATE, only by the lanes the line test
     // leaves (for the others nothing follows from the answer).  LATE is cheaper per object
     // but sends every lane through the branch at its own object: it pays with many lights.
     const bool tested = valid && first < 0 && idx != cur;
+#ifndef RT_PHASE_PROFILE
     if (COUNT && tested) { if (lr.thr == -__builtin_inff()) ++c_pln; else ++c_sph; }
+#endif
     if ((LATE ? valid : tested) && !line_miss_from_light(lr, fr)) {
         __asm__ volatile("" ::: "memory");  // the rest only for the lanes the line test leaves
+        RT_MARK("feeler_exact");
+        RT_ENTER(c_sph);
         const FRec gf = load_rec(fp + 8 * j);
         const DGeom g = load_geom(gp, j);
         double p;
         if ((!LATE || (first < 0 && idx != cur)) && !certain_miss(gf, fr) && test_collision(g, ip, fdir, p)) {
             // src/objects.h:40-46, here with the object's record still in scalar registers
             const V3 hp = ip + fdir * p;
-            const V3 no = unit((__double2hiint(g.r2) < 0) ? mk(g.q[0], g.q[1], g.q[2]) : (hp - mk(g.p[0], g.p[1], g.p[2])));
-            const double facing = -dot(no, fdir);
-            const double fres = mix_tenth(1 - facing, 0.0);
-            factor = (1 - fres) * g.transparency;
+            const V3 m = (__double2hiint(g.r2) < 0) ? mk(g.q[0], g.q[1], g.q[2]) : (hp - mk(g.p[0], g.p[1], g.p[2]));
+            factor = transmission(m, fdir, g.transparency);
             first = idx;
         }
     }
+    RT_MARK("feeler_loop");
 }
 
 template <int MW>
@@ -613,7 +681,7 @@ __device__ __forceinline__ void find_nearest(const KArgs& a, cdata_t geom, cfdat
 // receives its transmission factor.  `ffr` must hold filter_origin(ip).
 template <bool COUNT, bool TREE, bool LATE>
 __device__ __forceinline__ int shadow_feeler(const KArgs& a, cdata_t geom, cfdata_t fgeom, cfdata_t ltab, int li,
-                                             FilterRay& ffr, V3 ip, V3 fdir, int cur, bool cur_plane, double& occl,
+                                             FilterRay& ffr, V3 ip, V3 fdir, int cur, bool cur_plane, float& occl,
                                              uint32_t& c_sph, uint32_t& c_pln) {
     int first = -1;  // index of the first occluder in container order
     set_dir(ffr, fdir);
@@ -624,6 +692,7 @@ __device__ __forceinline__ int shadow_feeler(const KArgs& a, cdata_t geom, cfdat
         const int best = find_occluder_tree(a, geom, ffr, ip, fdir, cur, pa, pb);
         first = (best != 0x7fffffff) ? best : -1;
         if (first >= 0) occl = occluder_factor(a.geom + first, ip, fdir, pa, pb);
+#ifndef RT_PHASE_PROFILE
         if (COUNT) {
             // the tests the reference makes: objects 0..first (all when open), never `cur`
             const bool cur_pl = cur_plane;
@@ -633,6 +702,7 @@ __device__ __forceinline__ int shadow_feeler(const KArgs& a, cdata_t geom, cfdat
             c_pln += (uint32_t)planes;
             c_sph += (uint32_t)(tested - planes);
         }
+#endif
     } else {
         cfdata_t lp = ltab + (size_t)li * a.ltab_stride * 4;
         cfdata_t fp = fgeom;
@@ -677,10 +747,11 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
     const cfdata_t fgeom = (cfdata_t)(const float*)a.fgeom;
     const cfdata_t ltab = (cfdata_t)(const float*)a.ltab;
     const bool inside = have;
-    const int band = k / a.band_rows;
+    // band = k / band_rows without the division (KArgs::band_magic)
+    const int band = (a.band_rows == 1) ? k : (int)__umulhi((uint32_t)k, a.band_magic);
     const int y = (a.band_first + band * a.band_step) * a.band_rows + (k - band * a.band_rows);
 
-    const V3 bgr = mk(a.bgr_c[0], a.bgr_c[1], a.bgr_c[2]);
+    const F3 bgr = f3(a.bgr_c[0], a.bgr_c[1], a.bgr_c[2]);
 
     // Primary ray: src/main.cc:135-138, src/view_frustum.h:37-46, src/common.h:27-31.
     V3 o = mk(0.0, 0.0, 0.0);
@@ -689,38 +760,64 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
         const int xi = x - a.width / 2;
         const int yi = y - a.height / 2;
         V3 p1 = mk((xi + 0.5) * a.pw, (yi + 0.5) * a.ph, 1.0);
-        d = unit(p1 - o);
+        const V3 v = p1 - o;
+        // the host has checked the range guard of unit() for every pixel of the frame
+        if (a.primary_in_range) d = unit_mid(v, len2(v));
+        else d = unit(v);
     }
-    double w = 1.0;
+    float w = 1.0f;  // product of the reflection/refraction coefficients on the path (colour)
     uint32_t node = 1;
     int sp = 0;
-    double bottom[kStackFields] = {0, 0, 0, 0, 0, 0, 0, 0};  // stack entry 0, in registers
+    double bottom[kStackFields] = {0, 0, 0, 0, 0, 0, 0};  // stack entry 0, in registers
 
-    double cr = 0.0, cg = 0.0, cb = 0.0;
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
     int32_t first_hit = -1;
     uint32_t hmask[MW > 0 ? MW : 1] = {0};
     uint32_t smask[MW > 0 ? MW : 1] = {0};
+#ifdef RT_PHASE_PROFILE
+    // wave entries per phase: 0 iterations, 1 exact tests of the nearest-hit loop, 2 miss
+    // branch, 3 hit branch, 4 feelers, 5 exact tests of the feeler loops, 6 child rays built,
+    // 7 lane-iterations (per lane, not per wave)
+    uint32_t dummy = 0;
+    uint32_t &c_rays = dummy, &c_phits = dummy, &c_hits = dummy, &c_sph = cnt[1], &c_pln = dummy, &c_feel = dummy,
+             &c_occ = dummy, &c_refr = dummy, &c_fex = cnt[5];
+#define RT_EVENT(x) ((void)0)
+#else
     uint32_t &c_rays = cnt[0], &c_phits = cnt[1], &c_hits = cnt[2], &c_sph = cnt[3], &c_pln = cnt[4],
              &c_feel = cnt[5], &c_occ = cnt[6], &c_refr = cnt[7];
+    uint32_t& c_fex = c_sph;
+#define RT_EVENT(x) do { if (COUNT) { x; } } while (0)
+#endif
+    RT_MARK("prologue");
 
     while (have) {
+        RT_MARK("iter");
+        RT_ENTER(cnt[0]);
+#ifdef RT_PHASE_PROFILE
+        ++cnt[7];  // lane-iterations: against 64 x cnt[0] this is the share of lanes still walking
+#endif
         const int level = 32 - __builtin_clz(node);  // the reference's `depth`
         if (MW > 0) set_bit<MW>(smask, node);
-        if (COUNT) ++c_rays;
+        RT_EVENT(++c_rays);
 
         // ---- nearest hit, src/main.cc:37-47 ----
         int cur = -1;
         double nearest = __builtin_inf();
         find_nearest<COUNT, TREE>(a, geom, fgeom, o, d, nearest, cur, c_sph, c_pln);
+        RT_MARK("iter_tail");
         if (MW > 0 && level == 1) first_hit = cur;
 
         bool next_in_regs = false;
         if (cur < 0) {
+            RT_MARK("miss");
+            RT_ENTER(cnt[2]);
             // src/main.cc:49-53: the background, weighted by the path.
-            cr += w * bgr.x; cg += w * bgr.y; cb += w * bgr.z;
+            cr = __builtin_fmaf(w, bgr.x, cr); cg = __builtin_fmaf(w, bgr.y, cg); cb = __builtin_fmaf(w, bgr.z, cb);
         } else {
+            RT_MARK("hit_setup");
+            RT_ENTER(cnt[3]);
             if (MW > 0) set_bit<MW>(hmask, node);
-            if (COUNT) { ++c_hits; if (level == 1) ++c_phits; }
+            RT_EVENT(++c_hits; if (level == 1) ++c_phits);
 
             // per-lane gather of the hit object's records
             const DGeom* gsrc = a.geom + cur;
@@ -728,74 +825,84 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
             const double gr2 = gsrc->r2;
             const V3 gp = mk(gsrc->p[0], gsrc->p[1], gsrc->p[2]);
             const V3 gq = mk(gsrc->q[0], gsrc->q[1], gsrc->q[2]);
-            const V3 kd = mk(msrc->kd[0], msrc->kd[1], msrc->kd[2]);
-            const double m_refl = msrc->reflectivity;
-            const double m_tr = msrc->transparency;
+            const F3 kd = f3(msrc->kd[0], msrc->kd[1], msrc->kd[2]);
+            const float m_refl = msrc->reflectivity;
+            const float m_tr = msrc->transparency;
             double ri = msrc->refraction_index;
-            const double m_amb = msrc->ambient_intensity;
+            const float m_amb = msrc->ambient_intensity;
 
             // src/main.cc:55-65
             const V3 ip = o + d * nearest;
             V3 n = unit((__double2hiint(gr2) < 0) ? gq : (ip - gp));
             if (dot(n, d) > 0) {
                 n = -n;
-                ri = msrc->pad;  // 1.0 / refraction_index, src/main.cc:64
+                ri = msrc->inv_refraction_index;  // 1.0 / refraction_index, src/main.cc:64
             }
+            const F3 nf = f3((float)n.x, (float)n.y, (float)n.z);
 
             // ---- Object::Shade, src/objects.h:20-65 ----
-            double sr = 0.0, sg = 0.0, sb = 0.0;
+            float sr = 0.0f, sg = 0.0f, sb = 0.0f;
             FilterRay ffr = filter_origin(ip, a.scene_p1max);  // shared by the feelers of this hit
             for (int li = 0; li < a.n_lights; ++li) {
-                const DLight L = load_light(lights, li);
+                RT_MARK("feeler_dir");
+                RT_ENTER(cnt[4]);
+                const LightRec L = load_light(lights, li);
                 const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);  // feeler.dir
-                double occl = 1.0;
-                if (COUNT) ++c_feel;
+                float occl = 1.0f;
+                RT_EVENT(++c_feel);
+                RT_MARK("feeler_loop");
                 const int first = shadow_feeler<COUNT, TREE, LATE>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur,
-                                                             __double2hiint(gr2) < 0, occl, c_sph, c_pln);
-                if (COUNT && first >= 0) ++c_occ;
-                // src/objects.h:50-60 (light_dir is the same vector as feeler.dir).  The
-                // reference divides by length(normal) * length(light_dir): both are 1 to a
-                // few 2^-53, so the quotient is left out (colour only, below 1e-15).
-                double diff = __builtin_fabs(dot(n, fdir));
-                double tr_ = (kd.x * L.ci[0] * diff) * occl;
-                double tg_ = (kd.y * L.ci[1] * diff) * occl;
-                double tb_ = (kd.z * L.ci[2] * diff) * occl;
-                sr = sr + tr_; sr = (sr > 0.0) ? sr : 0.0;
-                sb = sb + tb_; sb = (sb > 0.0) ? sb : 0.0;
-                sg = sg + tg_; sg = (sg > 0.0) ? sg : 0.0;
+                                                             __double2hiint(gr2) < 0, occl, c_fex, c_pln);
+                RT_EVENT(if (first >= 0) ++c_occ);
+                RT_MARK("feeler_diffuse");
+                // src/objects.h:50-60 (light_dir is the same vector as feeler.dir, whose float
+                // image the filter holds).  The reference divides by length(normal) *
+                // length(light_dir): both are 1 to a few 2^-53, so the quotient is left out.
+                const float dk = __builtin_fabsf(dotf(nf, ffr.d)) * occl;
+                sr = __builtin_fmaxf(__builtin_fmaf(kd.x * L.ci[0], dk, sr), 0.0f);
+                sb = __builtin_fmaxf(__builtin_fmaf(kd.z * L.ci[2], dk, sb), 0.0f);
+                sg = __builtin_fmaxf(__builtin_fmaf(kd.y * L.ci[1], dk, sg), 0.0f);
             }
 
             // src/main.cc:70, 100-105
+            RT_MARK("combine");
             const V3 vt = div3(d, __builtin_fabs(dot(d, n)));
-            const double facing = -dot(n, d);
-            const double fresnel = mix_tenth(cube_rn(1 - facing), 1.0);
-            const double kt = (1 - fresnel) * m_tr;
-            const double kr = (1 - kt) * m_refl;
-            const double kdm = 1 - m_tr;
-            const double invd = a.inv_depth[level];
+            const float g1 = 1.0f + (float)dot(n, d);  // 1 - facing, facing = -dot(n, d)
+            const float fresnel = mix_tenth(g1 * g1 * g1, 1.0f);  // pow(1 - facing, 3), src/main.cc:101
+            const float kt = (1.0f - fresnel) * m_tr;
+            const float kr = (1.0f - kt) * m_refl;
+            const float kdm = 1.0f - m_tr;
+            const float amb = m_amb * a.inv_depth[level];
 
             // own colour: surface*kd + (bgr*ambient)*kd*(1/depth), src/main.cc:111-112
-            cr += w * (sr * kdm + ((bgr.x * m_amb) * kdm) * invd);
-            cg += w * (sg * kdm + ((bgr.y * m_amb) * kdm) * invd);
-            cb += w * (sb * kdm + ((bgr.z * m_amb) * kdm) * invd);
+            const float wk = w * kdm;
+            cr = __builtin_fmaf(wk, __builtin_fmaf(bgr.x, amb, sr), cr);
+            cg = __builtin_fmaf(wk, __builtin_fmaf(bgr.y, amb, sg), cg);
+            cb = __builtin_fmaf(wk, __builtin_fmaf(bgr.z, amb, sb), cb);
 
             // refraction test, src/main.cc:86-87
             const double kk = (ri * ri) * len2(vt) - len2(vt + n);
             const bool refr = kk > 0;
-            if (COUNT && refr) ++c_refr;
-            const double wr = w * kr, wt = w * kt;
+            RT_EVENT(if (refr) ++c_refr);
+            const float wr = w * kr, wt = w * kt;
 
             if (level + 1 >= a.max_depth) {
+                RT_MARK("children_last");
                 // both children stop at the depth limit and return the background
-                double ws = refr ? (wr + wt) : wr;
-                cr += ws * bgr.x; cg += ws * bgr.y; cb += ws * bgr.z;
+                const float ws = refr ? (wr + wt) : wr;
+                cr = __builtin_fmaf(ws, bgr.x, cr); cg = __builtin_fmaf(ws, bgr.y, cg); cb = __builtin_fmaf(ws, bgr.z, cb);
             } else {
+                RT_MARK("children");
+                RT_ENTER(cnt[6]);
                 if (refr) {
+                    RT_MARK("child_refraction");
                     // src/main.cc:88-93; Ray's constructor normalises again (src/common.h:24)
                     V3 td = (n + vt) * inv_sqrt_2r(kk) - n;
                     td = unit2(td);
                     V3 to = ip - n * 1e-4;
-                    const double ent[kStackFields] = {to.x, to.y, to.z, td.x, td.y, td.z, wt, (double)(2 * node + 1)};
+                    // the weight (float) and the node number share the last field
+                    const double ent[kStackFields] = {to.x, to.y, to.z, td.x, td.y, td.z,
+                                                      __hiloint2double((int)(2 * node + 1), __float_as_int(wt))};
                     if (sp == 0) {
 #pragma unroll
                         for (int f = 0; f < kStackFields; ++f) bottom[f] = ent[f];
@@ -813,6 +920,7 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                     ++sp;
                 }
                 // src/main.cc:75-79
+                RT_MARK("child_reflection");
                 V3 rd = unit2(vt + n * 2.0);
                 o = ip + n * 1e-4;
                 d = rd;
@@ -822,6 +930,7 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
             }
         }
 
+        RT_MARK("pop");
         if (!next_in_regs) {
             if (sp > 0) {
                 --sp;
@@ -842,14 +951,16 @@ __device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const i
                 }
                 o = mk(ent[0], ent[1], ent[2]);
                 d = mk(ent[3], ent[4], ent[5]);
-                w = ent[6];
-                node = (uint32_t)ent[7];
+                w = __int_as_float(__double2loint(ent[6]));
+                node = (uint32_t)__double2hiint(ent[6]);
             } else {
                 have = false;
             }
         }
     }
 
+    RT_MARK("epilogue");
+#undef RT_EVENT
     if (inside) {
         const size_t px = (size_t)k * a.width + x;
         uint8_t* dst = a.bgr + 3 * px;  // src/screen.h:62-64

@@ -13,6 +13,11 @@ using namespace exact;
 // the glass scene (16 lights, 13 % faster).
 constexpr int kLateMinLights = 4;
 
+// Waves per SIMD the image-only kernel is compiled for (its register budget).
+#ifndef RT_IMAGE_WAVES
+#define RT_IMAGE_WAVES 5
+#endif
+
 template <bool COUNT>
 __device__ __forceinline__ void flush_counters(const KArgs& a, const uint32_t (&cnt)[8], int lane) {
     if (COUNT) {
@@ -65,7 +70,7 @@ __device__ __forceinline__ int next_tile(unsigned int* queue, int lane) {
 // One wave per 8x8 pixel tile of the strip.  Without the deep stack the grid holds one wave
 // per tile; with it the grid is fixed and its waves take tiles from the queue.
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? 4 : 3, 4))) void whitted_kernel(KArgs a) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? RT_IMAGE_WAVES : 3, (MW == 0 && !COUNT && RT_IMAGE_WAVES > 4) ? RT_IMAGE_WAVES : 4))) void whitted_kernel(KArgs a) {
     extern __shared__ double lds_stack[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -246,10 +251,10 @@ __global__ void debug_occluder_kernel(KArgs a, int light, int self, const double
     const cdata_t geom = (cdata_t)(const double*)a.geom;
     const cdata_t lights = (cdata_t)(const double*)a.lights;
     const V3 ip = mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
-    const DLight L = load_light(lights, light);
+    const LightRec L = load_light(lights, light);
     const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);
     FilterRay ffr = filter_origin(ip, a.scene_p1max);
-    double occl = 1.0;
+    float occl = 1.0f;
     uint32_t c0 = 0, c1 = 0;
     const int first = shadow_feeler<false, TREE, false>(a, geom, (cfdata_t)(const float*)a.fgeom, (cfdata_t)(const float*)a.ltab,
                                                  light, ffr, ip, fdir, self, false, occl, c0, c1);

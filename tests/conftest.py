@@ -20,3 +20,18 @@ def tracer():
     t = DeviceTracer(0)
     yield t
     t.close()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """How close the 8-bit frames came to the checker's, over every parity comparison made."""
+    from tests import parity
+
+    if not parity.SEEN:
+        return
+    px = sum(n for _, n, _ in parity.SEEN)
+    same = sum(n * f for _, n, f in parity.SEEN)
+    worst = min(parity.SEEN, key=lambda r: r[2])
+    terminalreporter.write_line(
+        f"parity: {len(parity.SEEN)} frame comparisons, {px} pixels, {same / px:.6f} byte-identical overall; "
+        f"lowest {worst[2]:.6f} ({worst[0]}, {worst[1]} pixels)"
+    )

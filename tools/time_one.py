@@ -1,21 +1,42 @@
-import sys, os; sys.path.insert(0,'.')
-import numpy as np, torch
-from raytracer_amd import abi, scenes, device
-if os.environ.get("RT_LIB_OVERRIDE"): device.LIB_PATH = os.environ["RT_LIB_OVERRIDE"]
-from raytracer_amd.device import DeviceTracer
+"""Kernel time of whole-frame renders, HIP events around n back-to-back launches.
+usage: [RT_LIB_OVERRIDE=path/to/lib.so] time_one.py [WORKLOAD ...]   (default: the headline workload)"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from raytracer_amd import abi, device  # noqa: E402
+
+if os.environ.get("RT_LIB_OVERRIDE"):
+    device.LIB_PATH = os.path.abspath(os.environ["RT_LIB_OVERRIDE"])
+import bench  # noqa: E402
+from raytracer_amd.device import DeviceTracer  # noqa: E402
+
 t = DeviceTracer(0)
-def timeit(name, prims, lights, p, n=20):
+for name in (sys.argv[1:] or ["default_4k_d5"]):
+    builder, w, h, d = bench.WORKLOADS[name]
+    prims, lights = builder()
+    p = abi.make_params(w, h, d)
+    n = 100 if name.startswith("default") else 4
     t.upload_scene(prims, lights)
-    rows = abi.strip_rows(p); w = int(p['width'])
-    out = torch.zeros((rows, w, 3), dtype=torch.uint8, device='cuda')
+    out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
     st = torch.cuda.current_stream()
-    for _ in range(3): t.render_device(p, st.cuda_stream, out.data_ptr())
+    for _ in range(3 if n > 4 else 1):
+        t.render_device(p, st.cuda_stream, out.data_ptr())
     torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n): t.render_device(p, st.cuda_stream, out.data_ptr())
-    e1.record(); torch.cuda.synchronize()
-    print(f"{name}: {e0.elapsed_time(e1)/n:.4f} ms/frame", flush=True)
-pr, lt = scenes.default_scene()
-timeit("default 4K D5", pr, lt, abi.make_params(3840,2160,5), 100)
-timeit("default 4K D2", pr, lt, abi.make_params(3840,2160,2), 100)
+    best = 1e9
+    tot = 0.0
+    reps = 5 if n > 4 else 1
+    for _ in range(reps):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            t.render_device(p, st.cuda_stream, out.data_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        best = min(best, ms)
+        tot += ms
+    print(f"{os.path.basename(device.LIB_PATH)} {name}: mean {tot / reps:.4f} best {best:.4f} ms/frame", flush=True)
