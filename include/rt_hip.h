@@ -147,9 +147,11 @@ void rt_destroy(rt_ctx* ctx);
  * Device memory a context holds besides the scene and the staging buffers of rt_render
  * (which grow to the largest frame rendered): renders with max_depth > 5 keep part of their
  * ray stacks in a workspace of 42 MiB (256 CUs), one per stream such a render was enqueued
- * on, allocated at the first such render on that stream.  rt_trim() waits for the device to
- * go idle and frees these workspaces (a later render allocates afresh); a caller that
- * creates streams freely calls it now and then.  No counterpart in the reference.
+ * on, allocated at the first such render on that stream; renders of scenes that use the
+ * sphere tree (40 spheres or more) at smaller depths need 256 bytes per stream the same way.
+ * Renders of smaller scenes at max_depth <= 5 allocate nothing.  rt_trim() waits for the
+ * device to go idle and frees these workspaces (a later render allocates afresh); a caller
+ * that creates streams freely calls it now and then.  No counterpart in the reference.
  */
 int rt_trim(rt_ctx* ctx);
 
@@ -211,13 +213,13 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
 /*
  * rt_render_device for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc): same arguments, same
- * results, but a render with max_depth > 5 keeps its stack workspace in an array built into
- * the library (42 MiB + 256 bytes per GPU the library runs on, held until the process
+ * results, but a render that needs a workspace (max_depth > 5, or a scene with the sphere
+ * tree) keeps it in an array built into the library (42 MiB + 256 bytes per GPU the library runs on, held until the process
  * ends) instead of one allocated per stream, so the call never allocates or frees.  The
  * array holds the stacks of the largest launch grid at max_depth 8, the library's limit;
  * a larger max_depth is refused with RT_ERR_ARG like everywhere else, and the frame size
- * does not matter.  All calls on one GPU share the array: two such renders with
- * max_depth > 5 that overlap on one GPU (different streams or contexts) race; calls on one
+ * does not matter.  All calls on one GPU share the array: two such renders that use the
+ * workspace and overlap on one GPU (different streams or contexts) race; calls on one
  * stream, or separated by a synchronisation, do not.  It has no counterpart in the
  * reference.
  */

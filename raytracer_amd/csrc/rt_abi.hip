@@ -52,6 +52,7 @@ struct rt_ctx {
     // overlap.  Its size depends on the device only (workspace_bytes), never on the frame;
     // rt_trim() frees them all.
     std::map<void*, void*> workspaces;
+    std::map<void*, void*> queues;   // streams that only ever needed the tile queue (256 bytes)
     size_t workspace_bytes = 0;
     void* static_ws = nullptr;  // the library's built-in workspace on this device
     hipStream_t stream = nullptr;
@@ -118,11 +119,25 @@ int check_params(const rt_params* p) {
     return RT_OK;
 }
 
-// The deep-stack workspace of `stream` (allocated at the first deep launch on that stream).
-int stream_workspace(rt_ctx* ctx, void* stream, void** out) {
-    void*& w = ctx->workspaces[stream];
-    if (!w) RT_HIP_TRY(ctx, hipMalloc(&w, ctx->workspace_bytes));
-    *out = w;
+// The workspace of `stream` for launches with a fixed grid: tile queue + (deep: the stack
+// regions).  Allocated at the first such launch on that stream; a launch that only needs the
+// queue takes the header of the full workspace when the stream has one, else 256 bytes.
+int stream_workspace(rt_ctx* ctx, void* stream, bool deep, void** out) {
+    auto full = ctx->workspaces.find(stream);
+    if (full != ctx->workspaces.end() && full->second) {
+        *out = full->second;
+        return RT_OK;
+    }
+    if (deep) {
+        void* w = nullptr;
+        RT_HIP_TRY(ctx, hipMalloc(&w, ctx->workspace_bytes));
+        ctx->workspaces[stream] = w;
+        *out = w;
+        return RT_OK;
+    }
+    void*& q = ctx->queues[stream];
+    if (!q) RT_HIP_TRY(ctx, hipMalloc(&q, rt::kWorkspaceHeader));
+    *out = q;
     return RT_OK;
 }
 
@@ -130,12 +145,11 @@ int stream_workspace(rt_ctx* ctx, void* stream, void** out) {
 // `stream`; returns the grid size of the launch (0 when the depth needs no workspace).
 int attach_workspace(rt_ctx* ctx, rt::KArgs* args, int n, long long tiles, int max_depth, void* ws, hipStream_t stream,
                      int* deep_blocks) {
-    *deep_blocks = 0;
-    if (rt::stack_global_entries(max_depth) == 0) return RT_OK;
     *deep_blocks = rt::deep_grid_blocks(ctx->n_cus, tiles);
+    const bool deep = rt::stack_global_entries(max_depth) > 0;
     for (int i = 0; i < n; ++i) {
         args[i].tile_queue = static_cast<unsigned int*>(ws);
-        args[i].gstack = reinterpret_cast<double*>(static_cast<char*>(ws) + rt::kWorkspaceHeader);
+        args[i].gstack = deep ? reinterpret_cast<double*>(static_cast<char*>(ws) + rt::kWorkspaceHeader) : nullptr;
     }
     RT_HIP_TRY(ctx, hipMemsetAsync(ws, 0, rt::kWorkspaceHeader, stream));
     return RT_OK;
@@ -265,6 +279,9 @@ static void free_workspaces(rt_ctx* ctx) {
     for (auto& kv : ctx->workspaces)
         if (kv.second) (void)hipFree(kv.second);
     ctx->workspaces.clear();
+    for (auto& kv : ctx->queues)
+        if (kv.second) (void)hipFree(kv.second);
+    ctx->queues.clear();
 }
 
 void rt_destroy(rt_ctx* ctx) {
@@ -504,13 +521,14 @@ static int enqueue_render(rt_ctx* ctx, const rt_params* p, hipStream_t stream, v
     a.counters = reinterpret_cast<unsigned long long*>(d_counters);
     const bool emit = d_hit_id || d_hit_mask || d_spawn_mask;
     int deep_blocks = 0;
-    if (a.tiles_x > 0 && a.tiles_y > 0 && rt::stack_global_entries(a.max_depth) > 0) {
-        if (!ws && (rc = stream_workspace(ctx, stream, &ws)) != RT_OK) return rc;
+    const bool tree = use_tree(ctx, p);
+    if (a.tiles_x > 0 && a.tiles_y > 0 && (tree || rt::stack_global_entries(a.max_depth) > 0)) {
+        if (!ws && (rc = stream_workspace(ctx, stream, rt::stack_global_entries(a.max_depth) > 0, &ws)) != RT_OK) return rc;
         if ((rc = attach_workspace(ctx, &a, 1, static_cast<long long>(a.tiles_x) * a.tiles_y, a.max_depth, ws, stream,
                                    &deep_blocks)) != RT_OK)
             return rc;
     }
-    RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, use_tree(ctx, p), deep_blocks, stream));
+    RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, tree, deep_blocks, stream));
     return RT_OK;
 }
 
@@ -583,9 +601,9 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
         if (live == 0) continue;
         // the launch uses the first context's workspace of this stream
         int deep_blocks = 0;
-        if (rt::stack_global_entries(depth) > 0) {
+        if (tree || rt::stack_global_entries(depth) > 0) {
             void* ws = nullptr;
-            int rcg = stream_workspace(first, stream, &ws);
+            int rcg = stream_workspace(first, stream, rt::stack_global_entries(depth) > 0, &ws);
             if (rcg == RT_OK)
                 rcg = attach_workspace(first, b.a, live, tiles, depth, ws, static_cast<hipStream_t>(stream), &deep_blocks);
             if (rcg != RT_OK) return rcg;

@@ -59,6 +59,13 @@ namespace exact {
 // lets the compiler use scalar loads whenever the index is wave-uniform.
 #define RT_CONST __attribute__((address_space(4)))
 typedef const RT_CONST double* cdata_t;
+// The arguments of a render as they lie in the kernel-argument segment: every field is a
+// scalar load, also when a launch carries the arguments of several renders and the wave
+// picks one at run time.
+typedef const RT_CONST KArgs CArgs;
+// Code that reads a render's arguments is generic in their type AT: `const KArgs` (the
+// kernel's by-value argument: the compiler loads it once and keeps it in scalar registers)
+// where a launch has one render and no queue, CArgs where the wave picks a render at run time.
 
 // Record `i` of a table of 64-byte records, read through the constant address space.
 __device__ __forceinline__ DGeom load_geom(cdata_t t, int i) {
@@ -504,8 +511,8 @@ __device__ __forceinline__ void near_candidate(const FRec& gf, cdata_t geom, int
         cur = closer ? idx : cur;
     }
 }
-template <bool COUNT>
-__device__ __forceinline__ void find_nearest_tree(const KArgs& a, cdata_t geom, V3 o, V3 d, double& nearest, int& cur,
+template <bool COUNT, typename AT>
+__device__ __forceinline__ void find_nearest_tree(AT& a, cdata_t geom, V3 o, V3 d, double& nearest, int& cur,
                                                   uint32_t& c_sph, uint32_t& c_pln) {
     const FilterRay fr = filter_ray(o, d, a.scene_p1max);
 #ifndef RT_PHASE_PROFILE
@@ -543,7 +550,8 @@ __device__ __forceinline__ void feeler_candidate(const FRec& gf, cdata_t geom, i
         }
     }
 }
-__device__ __forceinline__ int find_occluder_tree(const KArgs& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur,
+template <typename AT>
+__device__ __forceinline__ int find_occluder_tree(AT& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur,
                                                   double& pa, double& pb) {
     int best = 0x7fffffff;
     cfdata_t pp = (cfdata_t)(const float*)a.planes;
@@ -650,8 +658,8 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 
 // The nearest hit of a ray over all objects (src/main.cc:37-47): `cur` = its index (-1 =
 // none), `nearest` = its t.
-template <bool COUNT, bool TREE>
-__device__ __forceinline__ void find_nearest(const KArgs& a, cdata_t geom, cfdata_t fgeom, V3 o, V3 d, double& nearest,
+template <bool COUNT, bool TREE, typename AT>
+__device__ __forceinline__ void find_nearest(AT& a, cdata_t geom, cfdata_t fgeom, V3 o, V3 d, double& nearest,
                                              int& cur, uint32_t& c_sph, uint32_t& c_pln) {
     if (TREE) {
         find_nearest_tree<COUNT>(a, geom, o, d, nearest, cur, c_sph, c_pln);
@@ -679,8 +687,8 @@ __device__ __forceinline__ void find_nearest(const KArgs& a, cdata_t geom, cfdat
 // One shadow feeler (src/objects.h:31-47): the index of the first occluder in container
 // order between `ip` and light `li` (never `cur`, the shaded object), or -1; `occl`
 // receives its transmission factor.  `ffr` must hold filter_origin(ip).
-template <bool COUNT, bool TREE, bool LATE>
-__device__ __forceinline__ int shadow_feeler(const KArgs& a, cdata_t geom, cfdata_t fgeom, cfdata_t ltab, int li,
+template <bool COUNT, bool TREE, bool LATE, typename AT>
+__device__ __forceinline__ int shadow_feeler(AT& a, cdata_t geom, cfdata_t fgeom, cfdata_t ltab, int li,
                                              FilterRay& ffr, V3 ip, V3 fdir, int cur, bool cur_plane, float& occl,
                                              uint32_t& c_sph, uint32_t& c_pln) {
     int first = -1;  // index of the first occluder in container order
@@ -732,251 +740,242 @@ __device__ __forceinline__ int shadow_feeler(const KArgs& a, cdata_t geom, cfdat
     return first;
 }
 
-// The whole walk of one pixel: lane-private except for the scalar scene loads.
-// (x, k) = column and strip row; `have` is false for lanes without a pixel.
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 64
+#endif
+constexpr int kRefillMin = RT_REFILL_MIN;
+
+// Where the pixels of a wave come from when a launch has a fixed grid.  All members are
+// wave-uniform.
+//
+// TileQueue (launches with a fixed grid): the launch's tiles - of one render, or of several
+// one after the other - are numbered 0..n_tiles-1 and handed out by an atomic counter, four
+// at a time (one at a time over the last quarter, which keeps the waves' finishing times
+// together).  A lane that has finished its pixel takes the next pixel of the wave's current
+// tile at once, so the lanes of a wave stay busy however different the ray trees of their
+// pixels are.  Pixels of two renders never share a wave: a tile of another render waits
+// until the lanes still walking have finished.
+struct TileQueue {
+    CArgs* renders;
+    const RT_CONST int32_t* tile_end;   // running totals of the renders' tiles; null = one render
+    unsigned int* queue;
+    int n_tiles;
+    int cur = 0;               // render of the walking lanes
+    int tile = 0, tiles_left = 0;  // tiles in hand: tile, tile+1, ... (not yet started)
+    int pos = 64;              // next pixel of the current tile, 64 = used up
+    int tx = 0, ty = 0;        // the current tile
+    int last = 0;              // the counter's value at the last fetch
+    bool exhausted = false;
+};
+
+// Give every lane without a pixel (`have` false) the next pixel of the queue, as long as
+// there are any; begin(x, k) starts a pixel's walk (and leaves `have` false for a pixel
+// outside the frame, whose lane then takes another).  Called by all lanes of the wave.
+template <typename Begin>
+__device__ __forceinline__ void take_pixels(TileQueue& f, CArgs*& ap, bool& have, Begin& begin) {
+    const int me = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    // New pixels are taken in batches of at least kRefillMin (lanes that start together stay
+    // in step with each other: their hit blocks and shadow loops run once for all of them)
+    if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(!have)) < kRefillMin) return;
+    for (;;) {
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
+        if (idle == 0ull) break;
+        if (f.pos == 64) {  // the current tile is used up: start the next one
+            if (f.tiles_left == 0) {
+                if (f.exhausted) break;
+                const unsigned int chunk = ((long long)f.last * 4 < (long long)f.n_tiles * 3) ? 4u : 1u;
+                unsigned int t = 0;
+                if (me == 0) t = atomicAdd(f.queue, chunk);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t >= (unsigned int)f.n_tiles) { f.exhausted = true; break; }
+                f.last = (int)t;
+                f.tile = (int)t;
+                const int rest = f.n_tiles - (int)t;
+                f.tiles_left = rest < (int)chunk ? rest : (int)chunk;
+            }
+            int r = 0, first = 0;
+            if (f.tile_end) {
+                while (f.tile >= f.tile_end[r]) ++r;
+                first = r ? f.tile_end[r - 1] : 0;
+            }
+            // pixels of two renders never share the wave
+            if (r != f.cur && __builtin_amdgcn_ballot_w64(have) != 0ull) break;
+            f.cur = r;
+            ap = f.renders + r;
+            const int tr = f.tile - first;
+            f.ty = tr / ap->tiles_x;
+            f.tx = tr - f.ty * ap->tiles_x;
+            f.pos = 0;
+            ++f.tile;
+            --f.tiles_left;
+        }
+        const int n_idle = __builtin_popcountll(idle);
+        const int m = (64 - f.pos) < n_idle ? (64 - f.pos) : n_idle;
+        // rank of this lane among the idle ones
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+        if (!have && rank < m) {
+            const int l = f.pos + rank;
+            begin(f.tx * kTile + (l & 7), f.ty * kTile + (l >> 3));
+        }
+        f.pos += m;
+    }
+}
+
+// The walks of a wave's pixels: lane-private except for the scalar scene loads.
 // MW = mask words kept per lane (0: neither hit_id nor masks are produced).
 // TREE = walk the sphere tree instead of the whole object list (large scenes).
 // DEEP = the stack may reach its global-memory part (max_depth > 3 + kStackLdsEntries);
 //        without it that code is left out, which the register allocation needs.
 // LATE = see feeler_slot() (container-order shadow loops of scenes with many lights).
-template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE = false>
-__device__ __forceinline__ void trace_pixel(const KArgs& a, const int x, const int k, bool have, double* stk,
-                                            double* gstk, const int lane, uint32_t (&cnt)[8]) {
+// The step itself (whitted_walk_step.inc.h) is shared by the two functions below.
+
+#ifdef RT_PHASE_PROFILE
+// wave entries per phase: 0 iterations, 1 exact tests of the nearest-hit loop, 2 miss
+// branch, 3 hit branch, 4 feelers, 5 exact tests of the feeler loops, 6 child rays built,
+// 7 lane-iterations (per lane, not per wave)
+#define RT_WALK_COUNTERS                                                                                      \
+    uint32_t dummy = 0;                                                                                       \
+    uint32_t &c_rays = dummy, &c_phits = dummy, &c_hits = dummy, &c_sph = cnt[1], &c_pln = dummy, &c_feel = dummy, \
+             &c_occ = dummy, &c_refr = dummy, &c_fex = cnt[5];
+#define RT_EVENT(x) ((void)0)
+#else
+#define RT_WALK_COUNTERS                                                                                      \
+    uint32_t &c_rays = cnt[0], &c_phits = cnt[1], &c_hits = cnt[2], &c_sph = cnt[3], &c_pln = cnt[4],       \
+             &c_feel = cnt[5], &c_occ = cnt[6], &c_refr = cnt[7];                                            \
+    uint32_t& c_fex = c_sph;
+#define RT_EVENT(x) do { if (COUNT) { x; } } while (0)
+#endif
+
+// The primary ray of pixel (x, row k of the strip): src/main.cc:135-138,
+// src/view_frustum.h:37-46, src/common.h:27-31 (origin 0, direction returned).
+template <typename AT>
+__device__ __forceinline__ V3 primary_direction(AT& a, int x, int k) {
+    // band = k / band_rows without the division (KArgs::band_magic)
+    const int band = (a.band_rows == 1) ? k : (int)__umulhi((uint32_t)k, a.band_magic);
+    const int y = (a.band_first + band * a.band_step) * a.band_rows + (k - band * a.band_rows);
+    const int xi = x - a.width / 2;
+    const int yi = y - a.height / 2;
+    const V3 v = mk((xi + 0.5) * a.pw, (yi + 0.5) * a.ph, 1.0) - mk(0.0, 0.0, 0.0);
+    // the host has checked the range guard of unit() for every pixel of the frame
+    if (a.primary_in_range) return unit_mid(v, len2(v));
+    return unit(v);
+}
+
+// Store a finished pixel: src/screen.h:62-64, src/color.h:27-29.
+template <int MW, typename AT>
+__device__ __forceinline__ void store_pixel(AT& a, int x, int k, float cr, float cg, float cb, int32_t first_hit,
+                                            const uint32_t (&hmask)[MW > 0 ? MW : 1],
+                                            const uint32_t (&smask)[MW > 0 ? MW : 1]) {
+    const size_t px = (size_t)k * a.width + x;
+    uint8_t* dst = a.bgr + 3 * px;
+    dst[0] = (uint8_t)to_u8(cb);
+    dst[1] = (uint8_t)to_u8(cg);
+    dst[2] = (uint8_t)to_u8(cr);
+    if (MW > 0) {
+        if (a.hit_id) a.hit_id[px] = first_hit;
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+            if (a.hit_mask) a.hit_mask[px * MW + i] = hmask[i];
+            if (a.spawn_mask) a.spawn_mask[px * MW + i] = smask[i];
+        }
+    }
+}
+
+// One wave, one 8x8 tile: (x, k) = this lane's column and strip row; `have` is false for
+// lanes without a pixel.
+template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, typename AT>
+__device__ __forceinline__ void trace_tile(AT& a, const int x, const int k, bool have, double* stk, double* gstk,
+                                           const int lane, uint32_t (&cnt)[8]) {
     const cdata_t geom = (cdata_t)(const double*)a.geom;
     const cdata_t lights = (cdata_t)(const double*)a.lights;
     const cfdata_t fgeom = (cfdata_t)(const float*)a.fgeom;
     const cfdata_t ltab = (cfdata_t)(const float*)a.ltab;
     const bool inside = have;
-    // band = k / band_rows without the division (KArgs::band_magic)
-    const int band = (a.band_rows == 1) ? k : (int)__umulhi((uint32_t)k, a.band_magic);
-    const int y = (a.band_first + band * a.band_step) * a.band_rows + (k - band * a.band_rows);
-
     const F3 bgr = f3(a.bgr_c[0], a.bgr_c[1], a.bgr_c[2]);
 
-    // Primary ray: src/main.cc:135-138, src/view_frustum.h:37-46, src/common.h:27-31.
     V3 o = mk(0.0, 0.0, 0.0);
-    V3 d;
-    {
-        const int xi = x - a.width / 2;
-        const int yi = y - a.height / 2;
-        V3 p1 = mk((xi + 0.5) * a.pw, (yi + 0.5) * a.ph, 1.0);
-        const V3 v = p1 - o;
-        // the host has checked the range guard of unit() for every pixel of the frame
-        if (a.primary_in_range) d = unit_mid(v, len2(v));
-        else d = unit(v);
-    }
+    V3 d = primary_direction(a, x, k);
     float w = 1.0f;  // product of the reflection/refraction coefficients on the path (colour)
     uint32_t node = 1;
     int sp = 0;
     double bottom[kStackFields] = {0, 0, 0, 0, 0, 0, 0};  // stack entry 0, in registers
-
     float cr = 0.0f, cg = 0.0f, cb = 0.0f;
     int32_t first_hit = -1;
     uint32_t hmask[MW > 0 ? MW : 1] = {0};
     uint32_t smask[MW > 0 ? MW : 1] = {0};
-#ifdef RT_PHASE_PROFILE
-    // wave entries per phase: 0 iterations, 1 exact tests of the nearest-hit loop, 2 miss
-    // branch, 3 hit branch, 4 feelers, 5 exact tests of the feeler loops, 6 child rays built,
-    // 7 lane-iterations (per lane, not per wave)
-    uint32_t dummy = 0;
-    uint32_t &c_rays = dummy, &c_phits = dummy, &c_hits = dummy, &c_sph = cnt[1], &c_pln = dummy, &c_feel = dummy,
-             &c_occ = dummy, &c_refr = dummy, &c_fex = cnt[5];
-#define RT_EVENT(x) ((void)0)
-#else
-    uint32_t &c_rays = cnt[0], &c_phits = cnt[1], &c_hits = cnt[2], &c_sph = cnt[3], &c_pln = cnt[4],
-             &c_feel = cnt[5], &c_occ = cnt[6], &c_refr = cnt[7];
-    uint32_t& c_fex = c_sph;
-#define RT_EVENT(x) do { if (COUNT) { x; } } while (0)
-#endif
+    RT_WALK_COUNTERS
     RT_MARK("prologue");
 
+#define RT_WALK_FINISHED have = false
     while (have) {
-        RT_MARK("iter");
-        RT_ENTER(cnt[0]);
-#ifdef RT_PHASE_PROFILE
-        ++cnt[7];  // lane-iterations: against 64 x cnt[0] this is the share of lanes still walking
-#endif
-        const int level = 32 - __builtin_clz(node);  // the reference's `depth`
-        if (MW > 0) set_bit<MW>(smask, node);
-        RT_EVENT(++c_rays);
-
-        // ---- nearest hit, src/main.cc:37-47 ----
-        int cur = -1;
-        double nearest = __builtin_inf();
-        find_nearest<COUNT, TREE>(a, geom, fgeom, o, d, nearest, cur, c_sph, c_pln);
-        RT_MARK("iter_tail");
-        if (MW > 0 && level == 1) first_hit = cur;
-
-        bool next_in_regs = false;
-        if (cur < 0) {
-            RT_MARK("miss");
-            RT_ENTER(cnt[2]);
-            // src/main.cc:49-53: the background, weighted by the path.
-            cr = __builtin_fmaf(w, bgr.x, cr); cg = __builtin_fmaf(w, bgr.y, cg); cb = __builtin_fmaf(w, bgr.z, cb);
-        } else {
-            RT_MARK("hit_setup");
-            RT_ENTER(cnt[3]);
-            if (MW > 0) set_bit<MW>(hmask, node);
-            RT_EVENT(++c_hits; if (level == 1) ++c_phits);
-
-            // per-lane gather of the hit object's records
-            const DGeom* gsrc = a.geom + cur;
-            const DMat* msrc = a.mat + cur;
-            const double gr2 = gsrc->r2;
-            const V3 gp = mk(gsrc->p[0], gsrc->p[1], gsrc->p[2]);
-            const V3 gq = mk(gsrc->q[0], gsrc->q[1], gsrc->q[2]);
-            const F3 kd = f3(msrc->kd[0], msrc->kd[1], msrc->kd[2]);
-            const float m_refl = msrc->reflectivity;
-            const float m_tr = msrc->transparency;
-            double ri = msrc->refraction_index;
-            const float m_amb = msrc->ambient_intensity;
-
-            // src/main.cc:55-65
-            const V3 ip = o + d * nearest;
-            V3 n = unit((__double2hiint(gr2) < 0) ? gq : (ip - gp));
-            if (dot(n, d) > 0) {
-                n = -n;
-                ri = msrc->inv_refraction_index;  // 1.0 / refraction_index, src/main.cc:64
-            }
-            const F3 nf = f3((float)n.x, (float)n.y, (float)n.z);
-
-            // ---- Object::Shade, src/objects.h:20-65 ----
-            float sr = 0.0f, sg = 0.0f, sb = 0.0f;
-            FilterRay ffr = filter_origin(ip, a.scene_p1max);  // shared by the feelers of this hit
-            for (int li = 0; li < a.n_lights; ++li) {
-                RT_MARK("feeler_dir");
-                RT_ENTER(cnt[4]);
-                const LightRec L = load_light(lights, li);
-                const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);  // feeler.dir
-                float occl = 1.0f;
-                RT_EVENT(++c_feel);
-                RT_MARK("feeler_loop");
-                const int first = shadow_feeler<COUNT, TREE, LATE>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur,
-                                                             __double2hiint(gr2) < 0, occl, c_fex, c_pln);
-                RT_EVENT(if (first >= 0) ++c_occ);
-                RT_MARK("feeler_diffuse");
-                // src/objects.h:50-60 (light_dir is the same vector as feeler.dir, whose float
-                // image the filter holds).  The reference divides by length(normal) *
-                // length(light_dir): both are 1 to a few 2^-53, so the quotient is left out.
-                const float dk = __builtin_fabsf(dotf(nf, ffr.d)) * occl;
-                sr = __builtin_fmaxf(__builtin_fmaf(kd.x * L.ci[0], dk, sr), 0.0f);
-                sb = __builtin_fmaxf(__builtin_fmaf(kd.z * L.ci[2], dk, sb), 0.0f);
-                sg = __builtin_fmaxf(__builtin_fmaf(kd.y * L.ci[1], dk, sg), 0.0f);
-            }
-
-            // src/main.cc:70, 100-105
-            RT_MARK("combine");
-            const V3 vt = div3(d, __builtin_fabs(dot(d, n)));
-            const float g1 = 1.0f + (float)dot(n, d);  // 1 - facing, facing = -dot(n, d)
-            const float fresnel = mix_tenth(g1 * g1 * g1, 1.0f);  // pow(1 - facing, 3), src/main.cc:101
-            const float kt = (1.0f - fresnel) * m_tr;
-            const float kr = (1.0f - kt) * m_refl;
-            const float kdm = 1.0f - m_tr;
-            const float amb = m_amb * a.inv_depth[level];
-
-            // own colour: surface*kd + (bgr*ambient)*kd*(1/depth), src/main.cc:111-112
-            const float wk = w * kdm;
-            cr = __builtin_fmaf(wk, __builtin_fmaf(bgr.x, amb, sr), cr);
-            cg = __builtin_fmaf(wk, __builtin_fmaf(bgr.y, amb, sg), cg);
-            cb = __builtin_fmaf(wk, __builtin_fmaf(bgr.z, amb, sb), cb);
-
-            // refraction test, src/main.cc:86-87
-            const double kk = (ri * ri) * len2(vt) - len2(vt + n);
-            const bool refr = kk > 0;
-            RT_EVENT(if (refr) ++c_refr);
-            const float wr = w * kr, wt = w * kt;
-
-            if (level + 1 >= a.max_depth) {
-                RT_MARK("children_last");
-                // both children stop at the depth limit and return the background
-                const float ws = refr ? (wr + wt) : wr;
-                cr = __builtin_fmaf(ws, bgr.x, cr); cg = __builtin_fmaf(ws, bgr.y, cg); cb = __builtin_fmaf(ws, bgr.z, cb);
-            } else {
-                RT_MARK("children");
-                RT_ENTER(cnt[6]);
-                if (refr) {
-                    RT_MARK("child_refraction");
-                    // src/main.cc:88-93; Ray's constructor normalises again (src/common.h:24)
-                    V3 td = (n + vt) * inv_sqrt_2r(kk) - n;
-                    td = unit2(td);
-                    V3 to = ip - n * 1e-4;
-                    // the weight (float) and the node number share the last field
-                    const double ent[kStackFields] = {to.x, to.y, to.z, td.x, td.y, td.z,
-                                                      __hiloint2double((int)(2 * node + 1), __float_as_int(wt))};
-                    if (sp == 0) {
-#pragma unroll
-                        for (int f = 0; f < kStackFields; ++f) bottom[f] = ent[f];
-                    } else {
-                        if (!DEEP || sp <= kStackLdsEntries) {
-                            double* e = stk + (size_t)(sp - 1) * kStackFields * 64;
-#pragma unroll
-                            for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
-                        } else {
-                            double* e = gstk + (size_t)(sp - 1 - kStackLdsEntries) * kStackFields * 64 + lane;
-#pragma unroll
-                            for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
-                        }
-                    }
-                    ++sp;
-                }
-                // src/main.cc:75-79
-                RT_MARK("child_reflection");
-                V3 rd = unit2(vt + n * 2.0);
-                o = ip + n * 1e-4;
-                d = rd;
-                w = wr;
-                node = 2 * node;
-                next_in_regs = true;
-            }
-        }
-
-        RT_MARK("pop");
-        if (!next_in_regs) {
-            if (sp > 0) {
-                --sp;
-                double ent[kStackFields];
-                if (sp == 0) {
-#pragma unroll
-                    for (int f = 0; f < kStackFields; ++f) ent[f] = bottom[f];
-                } else {
-                    if (!DEEP || sp <= kStackLdsEntries) {
-                        const double* e = stk + (size_t)(sp - 1) * kStackFields * 64;
-#pragma unroll
-                        for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
-                    } else {
-                        const double* e = gstk + (size_t)(sp - 1 - kStackLdsEntries) * kStackFields * 64 + lane;
-#pragma unroll
-                        for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
-                    }
-                }
-                o = mk(ent[0], ent[1], ent[2]);
-                d = mk(ent[3], ent[4], ent[5]);
-                w = __int_as_float(__double2loint(ent[6]));
-                node = (uint32_t)__double2hiint(ent[6]);
-            } else {
-                have = false;
-            }
-        }
+#include "whitted_walk_step.inc.h"
     }
+#undef RT_WALK_FINISHED
 
     RT_MARK("epilogue");
-#undef RT_EVENT
-    if (inside) {
-        const size_t px = (size_t)k * a.width + x;
-        uint8_t* dst = a.bgr + 3 * px;  // src/screen.h:62-64
-        dst[0] = (uint8_t)to_u8(cb);
-        dst[1] = (uint8_t)to_u8(cg);
-        dst[2] = (uint8_t)to_u8(cr);
+    if (inside) store_pixel<MW>(a, x, k, cr, cg, cb, first_hit, hmask, smask);
+}
+
+// One wave of a launch with a fixed grid: pixels from the tile queue until it is empty.
+template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
+__device__ __forceinline__ void trace_queue(TileQueue& feed, double* stk, double* gstk, const int lane,
+                                            uint32_t (&cnt)[8]) {
+    CArgs* ap = feed.renders + feed.cur;
+    int x = 0, k = 0;
+    bool have = false;
+    V3 o = mk(0.0, 0.0, 0.0), d = mk(0.0, 0.0, 1.0);
+    float w = 1.0f;
+    uint32_t node = 1;
+    int sp = 0;
+    double bottom[kStackFields] = {0, 0, 0, 0, 0, 0, 0};
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    int32_t first_hit = -1;
+    uint32_t hmask[MW > 0 ? MW : 1] = {0};
+    uint32_t smask[MW > 0 ? MW : 1] = {0};
+    RT_WALK_COUNTERS
+
+    // start the walk of pixel (nx, nk) in this lane
+    auto begin_pixel = [&](int nx, int nk) {
+        CArgs& a = *ap;
+        x = nx;
+        k = nk;
+        have = (nx < a.width) && (nk < a.rows);
+        o = mk(0.0, 0.0, 0.0);
+        d = primary_direction(a, nx, nk);
+        w = 1.0f;
+        node = 1;
+        sp = 0;
+        cr = 0.0f; cg = 0.0f; cb = 0.0f;
         if (MW > 0) {
-            if (a.hit_id) a.hit_id[px] = first_hit;
+            first_hit = -1;
 #pragma unroll
-            for (int i = 0; i < MW; ++i) {
-                if (a.hit_mask) a.hit_mask[px * MW + i] = hmask[i];
-                if (a.spawn_mask) a.spawn_mask[px * MW + i] = smask[i];
-            }
+            for (int i = 0; i < MW; ++i) { hmask[i] = 0; smask[i] = 0; }
+        }
+    };
+
+#define RT_WALK_FINISHED                                                     \
+    do {                                                                     \
+        store_pixel<MW>(a, x, k, cr, cg, cb, first_hit, hmask, smask);      \
+        have = false;                                                        \
+    } while (0)
+    for (;;) {
+        RT_MARK("refill");
+        take_pixels(feed, ap, have, begin_pixel);
+        if (!__any(have)) break;
+        if (have) {
+            CArgs& a = *ap;
+            const cdata_t geom = (cdata_t)(const double*)a.geom;
+            const cdata_t lights = (cdata_t)(const double*)a.lights;
+            const cfdata_t fgeom = (cfdata_t)(const float*)a.fgeom;
+            const cfdata_t ltab = (cfdata_t)(const float*)a.ltab;
+            const F3 bgr = f3(a.bgr_c[0], a.bgr_c[1], a.bgr_c[2]);
+#include "whitted_walk_step.inc.h"
         }
     }
+#undef RT_WALK_FINISHED
 }
+#undef RT_EVENT
+#undef RT_WALK_COUNTERS
 
 }  // namespace exact
 }  // namespace rt

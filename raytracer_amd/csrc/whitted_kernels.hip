@@ -18,8 +18,8 @@ constexpr int kLateMinLights = 4;
 #define RT_IMAGE_WAVES 5
 #endif
 
-template <bool COUNT>
-__device__ __forceinline__ void flush_counters(const KArgs& a, const uint32_t (&cnt)[8], int lane) {
+template <bool COUNT, typename AT>
+__device__ __forceinline__ void flush_counters(AT& a, const uint32_t (&cnt)[8], int lane) {
     if (COUNT) {
         unsigned long long s[8];
 #pragma unroll
@@ -56,42 +56,35 @@ hipError_t static_workspace(int device, void** ptr) {
 
 // Region `w` (a wave of the launch) of the global stack workspace, lane-major like the LDS part.
 // (w must be a wave-uniform value: the result then stays in scalar registers.)
-__device__ __forceinline__ double* wave_gstack(const KArgs& a, size_t w) {
+template <typename AT>
+__device__ __forceinline__ double* wave_gstack(AT& a, size_t w) {
     return a.gstack + w * (kDeepRegionBytes / sizeof(double));
 }
 
-// Deep-stack launches: the next tile of the queue, the same value in every lane.
-__device__ __forceinline__ int next_tile(unsigned int* queue, int lane) {
-    unsigned int t = 0;
-    if (lane == 0) t = atomicAdd(queue, 1u);
-    return (int)__builtin_amdgcn_readfirstlane(t);
-}
-
-// One wave per 8x8 pixel tile of the strip.  Without the deep stack the grid holds one wave
-// per tile; with it the grid is fixed and its waves take tiles from the queue.
+// Without the deep stack the grid holds one wave per 8x8 tile of the strip; with it the grid
+// is fixed and its waves take pixels from the tile queue (TileQueue).
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? RT_IMAGE_WAVES : 3, (MW == 0 && !COUNT && RT_IMAGE_WAVES > 4) ? RT_IMAGE_WAVES : 4))) void whitted_kernel(KArgs a) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? ((DEEP || TREE) ? 4 : RT_IMAGE_WAVES) : 3, (MW == 0 && !COUNT && !DEEP && !TREE && RT_IMAGE_WAVES > 4) ? RT_IMAGE_WAVES : 4))) void whitted_kernel(KArgs a_) {
     extern __shared__ double lds_stack[];
+    const KArgs& a = a_;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* stk = lds_stack + (size_t)wave * stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (DEEP) {
-        double* gstk = wave_gstack(a, (size_t)blockIdx.x * kWavesPerBlock + wave);
-        const int n_tiles = a.tiles_x * a.tiles_y;
-        for (int t = next_tile(a.tile_queue, lane); t < n_tiles; t = next_tile(a.tile_queue, lane)) {
-            const int ty = t / a.tiles_x;
-            const int tx = t - ty * a.tiles_x;
-            const int x = tx * kTile + (lane & 7);
-            const int k = ty * kTile + (lane >> 3);
-            trace_pixel<MW, COUNT, TREE, DEEP, LATE>(a, x, k, (x < a.width) && (k < a.rows), stk, gstk, lane, cnt);
-        }
+    if (DEEP || TREE) {
+        double* gstk = DEEP ? wave_gstack(a, (size_t)blockIdx.x * kWavesPerBlock + wave) : nullptr;
+        TileQueue feed;
+        feed.renders = (CArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // the one argument, where it lies
+        feed.tile_end = nullptr;
+        feed.queue = a.tile_queue;
+        feed.n_tiles = a.tiles_x * a.tiles_y;
+        trace_queue<MW, COUNT, TREE, DEEP, LATE>(feed, stk, gstk, lane, cnt);
     } else {
         const int tx = blockIdx.x * kWavesPerBlock + wave;  // a block = 4 tiles side by side
         const int ty = blockIdx.y;
         const int x = tx * kTile + (lane & 7);
         const int k = ty * kTile + (lane >> 3);  // row in strip order
-        trace_pixel<MW, COUNT, TREE, DEEP, LATE>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
+        trace_tile<MW, COUNT, TREE, DEEP, LATE>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
     }
     flush_counters<COUNT>(a, cnt, lane);
 }
@@ -101,8 +94,8 @@ static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t strea
     const int bx = (a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     if (bx <= 0 || a.tiles_y <= 0) return hipSuccess;
     const size_t lds = stack_lds_bytes(a.max_depth);
-    if (DEEP) {
-        if (deep_blocks < 1 || deep_blocks > kDeepMaxBlocks || !a.tile_queue || !a.gstack) return hipErrorInvalidValue;
+    if (DEEP || TREE) {
+        if (deep_blocks < 1 || deep_blocks > kDeepMaxBlocks || !a.tile_queue || (DEEP && !a.gstack)) return hipErrorInvalidValue;
         hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE>), dim3(deep_blocks), dim3(64 * kWavesPerBlock), lds, stream, a);
     } else {
         hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
@@ -116,38 +109,33 @@ static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t strea
 // once; with it the renders' tiles form one queue (tile_end = running totals).
 template <bool TREE, bool DEEP, bool LATE>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void whitted_batch_kernel(KBatch b, int n) {
+void whitted_batch_kernel(KBatch, int n) {
     extern __shared__ double lds_stack[];
+    const RT_CONST KBatch& b = *(const RT_CONST KBatch*)__builtin_amdgcn_kernarg_segment_ptr();  // the first argument
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (DEEP) {
+    if (DEEP || TREE) {
         // every render's stack entries sit at the offsets of the deepest render of the launch
         int depth = 0;
         for (int i = 0; i < n; ++i) depth = max(depth, b.a[i].max_depth);
         double* stk = lds_stack + (size_t)wave * stack_lds_entries(depth) * kStackFields * 64 + lane;
-        double* gstk = wave_gstack(b.a[0], (size_t)blockIdx.x * kWavesPerBlock + wave);
-        const int n_tiles = b.tile_end[n - 1];
-        for (int t = next_tile(b.a[0].tile_queue, lane); t < n_tiles; t = next_tile(b.a[0].tile_queue, lane)) {
-            int r = 0;
-            while (t >= b.tile_end[r]) ++r;  // wave-uniform
-            const KArgs& a = b.a[r];
-            const int tr = t - (r ? b.tile_end[r - 1] : 0);
-            const int ty = tr / a.tiles_x;
-            const int tx = tr - ty * a.tiles_x;
-            const int x = tx * kTile + (lane & 7);
-            const int k = ty * kTile + (lane >> 3);
-            trace_pixel<0, false, TREE, DEEP, LATE>(a, x, k, (x < a.width) && (k < a.rows), stk, gstk, lane, cnt);
-        }
+        double* gstk = DEEP ? wave_gstack(b.a[0], (size_t)blockIdx.x * kWavesPerBlock + wave) : nullptr;
+        TileQueue feed;
+        feed.renders = b.a;
+        feed.tile_end = b.tile_end;
+        feed.queue = b.a[0].tile_queue;
+        feed.n_tiles = b.tile_end[n - 1];
+        trace_queue<0, false, TREE, DEEP, LATE>(feed, stk, gstk, lane, cnt);
     } else {
-        const KArgs& a = b.a[blockIdx.z];
+        CArgs& a = b.a[blockIdx.z];
         if ((int)blockIdx.y >= a.tiles_y || (int)(blockIdx.x * kWavesPerBlock) >= a.tiles_x) return;
         double* stk = lds_stack + (size_t)wave * stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
         const int tx = blockIdx.x * kWavesPerBlock + wave;
         const int ty = blockIdx.y;
         const int x = tx * kTile + (lane & 7);
         const int k = ty * kTile + (lane >> 3);
-        trace_pixel<0, false, TREE, DEEP, LATE>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
+        trace_tile<0, false, TREE, DEEP, LATE>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
     }
 }
 
@@ -162,9 +150,10 @@ hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, int deep_bloc
     if (n <= 0 || bx <= 0 || by <= 0) return hipSuccess;
     const size_t lds = stack_lds_bytes(depth);
     const bool deep = stack_global_entries(depth) > 0;
-    if (deep && (deep_blocks < 1 || deep_blocks > kDeepMaxBlocks || !b.a[0].tile_queue || !b.a[0].gstack))
+    const bool queue = deep || tree;
+    if (queue && (deep_blocks < 1 || deep_blocks > kDeepMaxBlocks || !b.a[0].tile_queue || (deep && !b.a[0].gstack)))
         return hipErrorInvalidValue;
-    const dim3 grid = deep ? dim3(deep_blocks) : dim3(bx, by, n);
+    const dim3 grid = queue ? dim3(deep_blocks) : dim3(bx, by, n);
     const dim3 block(64 * kWavesPerBlock);
     bool late = !tree;  // every render of the batch must have many lights
     for (int i = 0; i < n; ++i) late = late && b.a[i].n_lights >= kLateMinLights;

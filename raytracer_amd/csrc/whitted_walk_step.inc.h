@@ -1,0 +1,171 @@
+// One step of a pixel's walk: the ray in (o, d) with path weight w at tree node `node` is
+// traced, shaded and replaced by its reflection child or by the ray on top of the stack; when
+// nothing is left the step ends with RT_WALK_FINISHED.  This text is the body of the loops in
+// whitted_exact.inc.h (included there twice: once per way a wave gets its pixels) and uses
+// their variables; it is not a header of its own.
+        RT_MARK("iter");
+        RT_ENTER(cnt[0]);
+#ifdef RT_PHASE_PROFILE
+        ++cnt[7];  // lane-iterations: against 64 x cnt[0] this is the share of lanes still walking
+#endif
+        const int level = 32 - __builtin_clz(node);  // the reference's `depth`
+        if (MW > 0) set_bit<MW>(smask, node);
+        RT_EVENT(++c_rays);
+
+        // ---- nearest hit, src/main.cc:37-47 ----
+        int cur = -1;
+        double nearest = __builtin_inf();
+        find_nearest<COUNT, TREE>(a, geom, fgeom, o, d, nearest, cur, c_sph, c_pln);
+        RT_MARK("iter_tail");
+        if (MW > 0 && level == 1) first_hit = cur;
+
+        bool next_in_regs = false;
+        if (cur < 0) {
+            RT_MARK("miss");
+            RT_ENTER(cnt[2]);
+            // src/main.cc:49-53: the background, weighted by the path.
+            cr = __builtin_fmaf(w, bgr.x, cr); cg = __builtin_fmaf(w, bgr.y, cg); cb = __builtin_fmaf(w, bgr.z, cb);
+        } else {
+            RT_MARK("hit_setup");
+            RT_ENTER(cnt[3]);
+            if (MW > 0) set_bit<MW>(hmask, node);
+            RT_EVENT(++c_hits; if (level == 1) ++c_phits);
+
+            // per-lane gather of the hit object's records
+            const DGeom* gsrc = a.geom + cur;
+            const DMat* msrc = a.mat + cur;
+            const double gr2 = gsrc->r2;
+            const V3 gp = mk(gsrc->p[0], gsrc->p[1], gsrc->p[2]);
+            const V3 gq = mk(gsrc->q[0], gsrc->q[1], gsrc->q[2]);
+            const F3 kd = f3(msrc->kd[0], msrc->kd[1], msrc->kd[2]);
+            const float m_refl = msrc->reflectivity;
+            const float m_tr = msrc->transparency;
+            double ri = msrc->refraction_index;
+            const float m_amb = msrc->ambient_intensity;
+
+            // src/main.cc:55-65
+            const V3 ip = o + d * nearest;
+            V3 n = unit((__double2hiint(gr2) < 0) ? gq : (ip - gp));
+            if (dot(n, d) > 0) {
+                n = -n;
+                ri = msrc->inv_refraction_index;  // 1.0 / refraction_index, src/main.cc:64
+            }
+            const F3 nf = f3((float)n.x, (float)n.y, (float)n.z);
+
+            // ---- Object::Shade, src/objects.h:20-65 ----
+            float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+            FilterRay ffr = filter_origin(ip, a.scene_p1max);  // shared by the feelers of this hit
+            for (int li = 0; li < a.n_lights; ++li) {
+                RT_MARK("feeler_dir");
+                RT_ENTER(cnt[4]);
+                const LightRec L = load_light(lights, li);
+                const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);  // feeler.dir
+                float occl = 1.0f;
+                RT_EVENT(++c_feel);
+                RT_MARK("feeler_loop");
+                const int first = shadow_feeler<COUNT, TREE, LATE>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur,
+                                                             __double2hiint(gr2) < 0, occl, c_fex, c_pln);
+                RT_EVENT(if (first >= 0) ++c_occ);
+                RT_MARK("feeler_diffuse");
+                // src/objects.h:50-60 (light_dir is the same vector as feeler.dir, whose float
+                // image the filter holds).  The reference divides by length(normal) *
+                // length(light_dir): both are 1 to a few 2^-53, so the quotient is left out.
+                const float dk = __builtin_fabsf(dotf(nf, ffr.d)) * occl;
+                sr = __builtin_fmaxf(__builtin_fmaf(kd.x * L.ci[0], dk, sr), 0.0f);
+                sb = __builtin_fmaxf(__builtin_fmaf(kd.z * L.ci[2], dk, sb), 0.0f);
+                sg = __builtin_fmaxf(__builtin_fmaf(kd.y * L.ci[1], dk, sg), 0.0f);
+            }
+
+            // src/main.cc:70, 100-105
+            RT_MARK("combine");
+            const V3 vt = div3(d, __builtin_fabs(dot(d, n)));
+            const float g1 = 1.0f + (float)dot(n, d);  // 1 - facing, facing = -dot(n, d)
+            const float fresnel = mix_tenth(g1 * g1 * g1, 1.0f);  // pow(1 - facing, 3), src/main.cc:101
+            const float kt = (1.0f - fresnel) * m_tr;
+            const float kr = (1.0f - kt) * m_refl;
+            const float kdm = 1.0f - m_tr;
+            const float amb = m_amb * a.inv_depth[level];
+
+            // own colour: surface*kd + (bgr*ambient)*kd*(1/depth), src/main.cc:111-112
+            const float wk = w * kdm;
+            cr = __builtin_fmaf(wk, __builtin_fmaf(bgr.x, amb, sr), cr);
+            cg = __builtin_fmaf(wk, __builtin_fmaf(bgr.y, amb, sg), cg);
+            cb = __builtin_fmaf(wk, __builtin_fmaf(bgr.z, amb, sb), cb);
+
+            // refraction test, src/main.cc:86-87
+            const double kk = (ri * ri) * len2(vt) - len2(vt + n);
+            const bool refr = kk > 0;
+            RT_EVENT(if (refr) ++c_refr);
+            const float wr = w * kr, wt = w * kt;
+
+            if (level + 1 >= a.max_depth) {
+                RT_MARK("children_last");
+                // both children stop at the depth limit and return the background
+                const float ws = refr ? (wr + wt) : wr;
+                cr = __builtin_fmaf(ws, bgr.x, cr); cg = __builtin_fmaf(ws, bgr.y, cg); cb = __builtin_fmaf(ws, bgr.z, cb);
+            } else {
+                RT_MARK("children");
+                RT_ENTER(cnt[6]);
+                if (refr) {
+                    RT_MARK("child_refraction");
+                    // src/main.cc:88-93; Ray's constructor normalises again (src/common.h:24)
+                    V3 td = (n + vt) * inv_sqrt_2r(kk) - n;
+                    td = unit2(td);
+                    V3 to = ip - n * 1e-4;
+                    // the weight (float) and the node number share the last field
+                    const double ent[kStackFields] = {to.x, to.y, to.z, td.x, td.y, td.z,
+                                                      __hiloint2double((int)(2 * node + 1), __float_as_int(wt))};
+                    if (sp == 0) {
+#pragma unroll
+                        for (int f = 0; f < kStackFields; ++f) bottom[f] = ent[f];
+                    } else {
+                        if (!DEEP || sp <= kStackLdsEntries) {
+                            double* e = stk + (size_t)(sp - 1) * kStackFields * 64;
+#pragma unroll
+                            for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
+                        } else {
+                            double* e = gstk + (size_t)(sp - 1 - kStackLdsEntries) * kStackFields * 64 + lane;
+#pragma unroll
+                            for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
+                        }
+                    }
+                    ++sp;
+                }
+                // src/main.cc:75-79
+                RT_MARK("child_reflection");
+                V3 rd = unit2(vt + n * 2.0);
+                o = ip + n * 1e-4;
+                d = rd;
+                w = wr;
+                node = 2 * node;
+                next_in_regs = true;
+            }
+        }
+
+        RT_MARK("pop");
+        if (!next_in_regs) {
+            if (sp > 0) {
+                --sp;
+                double ent[kStackFields];
+                if (sp == 0) {
+#pragma unroll
+                    for (int f = 0; f < kStackFields; ++f) ent[f] = bottom[f];
+                } else {
+                    if (!DEEP || sp <= kStackLdsEntries) {
+                        const double* e = stk + (size_t)(sp - 1) * kStackFields * 64;
+#pragma unroll
+                        for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
+                    } else {
+                        const double* e = gstk + (size_t)(sp - 1 - kStackLdsEntries) * kStackFields * 64 + lane;
+#pragma unroll
+                        for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
+                    }
+                }
+                o = mk(ent[0], ent[1], ent[2]);
+                d = mk(ent[3], ent[4], ent[5]);
+                w = __int_as_float(__double2loint(ent[6]));
+                node = (uint32_t)__double2hiint(ent[6]);
+            } else {
+                RT_WALK_FINISHED;
+            }
+        }
