@@ -377,6 +377,16 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         m.refraction_index = s.refraction_index;
         m.ambient_intensity = static_cast<float>(s.ambient_intensity);
         m.inv_refraction_index = 1.0 / s.refraction_index;  // src/main.cc:64, the same division done once
+        if (s.type == RT_PRIM_PLANE) {
+            // gmtl::makeNormal(normal_): length as a running sum from 0, three divisions, skipped
+            // for a zero length - the arithmetic of Plane::calcNormal, done here once
+            double l2 = 0.0;
+            l2 += s.q[0] * s.q[0];
+            l2 += s.q[1] * s.q[1];
+            l2 += s.q[2] * s.q[2];
+            const double len = std::sqrt(l2);
+            for (int c = 0; c < 3; ++c) m.plane_normal[c] = (len != 0.0) ? s.q[c] / len : s.q[c];
+        }
     }
     for (int i = 0; i < n_lights; ++i) {
         for (int c = 0; c < 3; ++c)

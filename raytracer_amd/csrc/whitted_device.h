@@ -34,7 +34,8 @@ struct DMat {
     float reflectivity;
     float transparency;
     float ambient_intensity;
-    float pad[6];
+    double plane_normal[3];  // planes: calcNormal's result, makeNormal(normal_) (src/objects.h:104-106),
+                             // the same for every hit and therefore worked out once at upload
 };
 
 // One point light; ci = light_color * double(intensity) (src/objects.h:54-56), rounded to

@@ -527,6 +527,7 @@ __device__ __forceinline__ void find_nearest_tree(AT& a, cdata_t geom, V3 o, V3 
     int i = 0;
     while (i < a.n_nodes) {
         const FNode nd = load_node(tree + 8 * i);
+        RT_ENTER(c_sph);  // (analysis builds: nodes visited)
         if (nd.tag < 0) {  // leaf: the record is the sphere itself
             near_candidate<COUNT>(leaf_rec(nd), geom, ~nd.tag, fr, o, d, nearest, cur);
             ++i;
@@ -552,7 +553,7 @@ __device__ __forceinline__ void feeler_candidate(const FRec& gf, cdata_t geom, i
 }
 template <typename AT>
 __device__ __forceinline__ int find_occluder_tree(AT& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur,
-                                                  double& pa, double& pb) {
+                                                  double& pa, double& pb, uint32_t& c_nodes) {
     int best = 0x7fffffff;
     cfdata_t pp = (cfdata_t)(const float*)a.planes;
     for (int k = 0; k < a.n_planes; ++k, pp += 8) {
@@ -563,6 +564,7 @@ __device__ __forceinline__ int find_occluder_tree(AT& a, cdata_t geom, const Fil
     int i = 0;
     while (i < a.n_nodes) {
         const FNode nd = load_node(tree + 8 * i);
+        RT_ENTER(c_nodes);  // (analysis builds: nodes visited)
         if (nd.tag < 0) {
             feeler_candidate(leaf_rec(nd), geom, ~nd.tag, fr, ip, fdir, cur, best, pa, pb);
             ++i;
@@ -697,7 +699,7 @@ __device__ __forceinline__ int shadow_feeler(AT& a, cdata_t geom, cfdata_t fgeom
         // the walk meets occluders in any order: it only keeps the one with the
         // smallest index, whose factor is worked out afterwards
         double pa = 0.0, pb = 0.0;  // see collides()
-        const int best = find_occluder_tree(a, geom, ffr, ip, fdir, cur, pa, pb);
+        const int best = find_occluder_tree(a, geom, ffr, ip, fdir, cur, pa, pb, c_sph);
         first = (best != 0x7fffffff) ? best : -1;
         if (first >= 0) occl = occluder_factor(a.geom + first, ip, fdir, pa, pb);
 #ifndef RT_PHASE_PROFILE

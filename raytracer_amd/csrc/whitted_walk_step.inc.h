@@ -36,7 +36,7 @@
             const DMat* msrc = a.mat + cur;
             const double gr2 = gsrc->r2;
             const V3 gp = mk(gsrc->p[0], gsrc->p[1], gsrc->p[2]);
-            const V3 gq = mk(gsrc->q[0], gsrc->q[1], gsrc->q[2]);
+            const V3 gq = mk(msrc->plane_normal[0], msrc->plane_normal[1], msrc->plane_normal[2]);
             const F3 kd = f3(msrc->kd[0], msrc->kd[1], msrc->kd[2]);
             const float m_refl = msrc->reflectivity;
             const float m_tr = msrc->transparency;
@@ -45,7 +45,14 @@
 
             // src/main.cc:55-65
             const V3 ip = o + d * nearest;
-            V3 n = unit((__double2hiint(gr2) < 0) ? gq : (ip - gp));
+            // calcNormal: a plane's is a constant of the plane (worked out at upload), a
+            // sphere's is normalised here - when any lane of the wave has hit a sphere
+            const bool on_plane = __double2hiint(gr2) < 0;
+            V3 n = gq;
+            if (__any(!on_plane)) {
+                const V3 ns = unit(on_plane ? gq : (ip - gp));
+                n = on_plane ? gq : ns;
+            }
             if (dot(n, d) > 0) {
                 n = -n;
                 ri = msrc->inv_refraction_index;  // 1.0 / refraction_index, src/main.cc:64
