@@ -38,10 +38,6 @@
             const V3 gp = mk(gsrc->p[0], gsrc->p[1], gsrc->p[2]);
             const V3 gq = mk(msrc->plane_normal[0], msrc->plane_normal[1], msrc->plane_normal[2]);
             const F3 kd = f3(msrc->kd[0], msrc->kd[1], msrc->kd[2]);
-            const float m_refl = msrc->reflectivity;
-            const float m_tr = msrc->transparency;
-            double ri = msrc->refraction_index;
-            const float m_amb = msrc->ambient_intensity;
 
             // src/main.cc:55-65
             const V3 ip = o + d * nearest;
@@ -53,10 +49,8 @@
                 const V3 ns = unit(on_plane ? gq : (ip - gp));
                 n = on_plane ? gq : ns;
             }
-            if (dot(n, d) > 0) {
-                n = -n;
-                ri = msrc->inv_refraction_index;  // 1.0 / refraction_index, src/main.cc:64
-            }
+            const bool flipped = dot(n, d) > 0;  // src/main.cc:62-65
+            if (flipped) n = -n;
             const F3 nf = f3((float)n.x, (float)n.y, (float)n.z);
 
             // ---- Object::Shade, src/objects.h:20-65 ----
@@ -82,6 +76,15 @@
                 sb = __builtin_fmaxf(__builtin_fmaf(kd.z * L.ci[2], dk, sb), 0.0f);
                 sg = __builtin_fmaxf(__builtin_fmaf(kd.y * L.ci[1], dk, sg), 0.0f);
             }
+
+            // The material values the rest needs are fetched only now: registers are scarce
+            // while the shadow loops run.  refraction_index, or 1.0 / refraction_index after
+            // a flip (src/main.cc:64).
+            __asm__ volatile("" : "+v"(msrc));
+            const float m_refl = msrc->reflectivity;
+            const float m_tr = msrc->transparency;
+            const float m_amb = msrc->ambient_intensity;
+            const double ri = flipped ? msrc->inv_refraction_index : msrc->refraction_index;
 
             // src/main.cc:70, 100-105
             RT_MARK("combine");
