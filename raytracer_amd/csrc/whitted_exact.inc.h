@@ -361,31 +361,35 @@ __device__ __forceinline__ bool line_miss_from_light(const LRec& l, const Filter
 }
 // True when the reference's test of this ray against the primitive certainly returns
 // nullopt.  ~15 float operations, no division, no square root.
+__device__ __forceinline__ bool certain_miss_sphere(float c0, float c1, float c2, float r2, const FilterRay& r) {
+    const F3 L = f3(c0, c1, c2) - r.o;
+    const float tca = dotf(L, r.d);
+    const F3 P = f3(__builtin_fmaf(-tca, r.d.x, L.x), __builtin_fmaf(-tca, r.d.y, L.y), __builtin_fmaf(-tca, r.d.z, L.z));
+    const float d2 = dotf(P, P);
+    return (tca < -r.etb) | (__builtin_fmaf(-2.01f, r2, d2) > r.far2);
+}
 __device__ __forceinline__ bool certain_miss(const FRec& g, const FilterRay& r) {
-    const F3 a = f3(g.a0, g.a1, g.a2);
     if (__float_as_int(g.r2) < 0) {  // plane (wave-uniform)
+        const F3 a = f3(g.a0, g.a1, g.a2);
         const float denom = dotf(r.d, a);
         const float num = g.b0 - dotf(r.o, a);
         const float en = r.en_ray + g.b1;
         // both certainly non-zero, and of opposite signs (no short-circuit: three compares)
         return (__builtin_fabsf(num) > en) & (__builtin_fabsf(denom) > r.eden) & (num * denom < 0.0f);
     }
-    const F3 L = a - r.o;
-    const float tca = dotf(L, r.d);
-    const F3 P = f3(__builtin_fmaf(-tca, r.d.x, L.x), __builtin_fmaf(-tca, r.d.y, L.y), __builtin_fmaf(-tca, r.d.z, L.z));
-    const float d2 = dotf(P, P);
-    return tca < -r.etb || __builtin_fmaf(-2.01f, g.r2, d2) > r.far2;
+    return certain_miss_sphere(g.a0, g.a1, g.a2, g.r2, r);
 }
 
 
 // Plane::TestCollision (src/objects.h:91-102) / Sphere::TestCollision
 // (src/objects.h:124-138) of a broadcast primitive against this lane's ray.
 // `g` is wave-uniform, so the type branch is.
+template <bool SPHERE = false>  // SPHERE: the caller knows the primitive is a sphere (a leaf of the tree)
 __device__ __forceinline__ bool test_collision(const DGeom& g, V3 o, V3 d, double& t) {
     // Written without early returns: the lanes that get here have passed the filter, so
     // most of them hit, and a NaN or infinity computed on the others is never used.  The
     // conditions are the reference's, negated the way its early returns negate them.
-    if (__double2hiint(g.r2) < 0) {
+    if (!SPHERE && __double2hiint(g.r2) < 0) {
         const V3 n = mk(g.q[0], g.q[1], g.q[2]);
         const double denom = dot(d, n);
         const V3 diff = mk(g.p[0], g.p[1], g.p[2]) - o;
@@ -410,8 +414,9 @@ __device__ __forceinline__ bool test_collision(const DGeom& g, V3 o, V3 d, doubl
 // root for that (src/objects.h:126-130 return before it), a plane needs its division.
 // On a hit (pa, pb) keep what the value follows from: a plane's t and -1, or a sphere's
 // tca and r2 - d2 >= 0 (collision_value() finishes the arithmetic of src/objects.h:131-137).
+template <bool SPHERE = false>
 __device__ __forceinline__ bool collides(const DGeom& g, V3 o, V3 d, double& pa, double& pb) {
-    if (__double2hiint(g.r2) < 0) {
+    if (!SPHERE && __double2hiint(g.r2) < 0) {
         double t = 0.0;
         const bool hit = test_collision(g, o, d, t);
         pa = hit ? t : pa;
@@ -454,8 +459,8 @@ __device__ __forceinline__ float occluder_factor(const DGeom* og, V3 ip, V3 fdir
 // ---- sphere tree (large scenes) -------------------------------------------------------
 // Interior nodes of the tree built by sphere_tree.h are boxes (float centre C, half extents
 // h, rounded outwards on the host so that the box contains every member sphere).
-// box_miss() is true when the reference's test certainly returns nullopt for EVERY sphere
-// below the node.  With m = C - o, Sb >= |o|_1 + |C|_1 + |h|_1, U = 2^-24:
+// box_miss() returns the mask of the lanes for whose ray the reference's test certainly
+// returns nullopt for EVERY sphere below the node.  With m = C - o, Sb >= |o|_1 + |C|_1 + |h|_1, U = 2^-24:
 //   (A) the ray's line passes the box at a distance: for one of the axes n = d x e_k,
 //       |m . n| - sum_j h_j |n_j| > ecross.  In float the left side is off by at most
 //       24 U Sb (m: 2 U Sb; d: 2U; five roundings); ecross = 32 U Sb leaves a clearance of
@@ -475,41 +480,57 @@ __device__ __forceinline__ FNode load_node(cfdata_t p) {
     n.h0 = p[3]; n.h1 = p[4]; n.h2 = p[5];
     n.skip = __float_as_int(p[6]);
     n.tag = __float_as_int(p[7]);
+    // all eight words are wanted here: keeps them one load (parts of the record moved into the
+    // branch that uses them would be fetched by a second, dependent load)
+    __asm__ volatile("" ::"s"(n.c0), "s"(n.c1), "s"(n.c2), "s"(n.h0), "s"(n.h1), "s"(n.h2), "s"(n.skip), "s"(n.tag));
     return n;
 }
-__device__ __forceinline__ FRec leaf_rec(const FNode& n) {
-    FRec g;
-    g.a0 = n.c0; g.a1 = n.c1; g.a2 = n.c2; g.r2 = n.h0;
-    g.b0 = 0.0f; g.b1 = 0.0f;
-    return g;
-}
-__device__ __forceinline__ bool box_miss(const FNode& n, const FilterRay& r) {
+__device__ __forceinline__ unsigned long long box_miss(const FNode& n, const FilterRay& r) {
     const F3 m = f3(n.c0, n.c1, n.c2) - r.o;
     const F3 d = r.d;
     const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
-    // separating axes d x e_x, d x e_y, d x e_z
-    const float sx = __builtin_fabsf(__builtin_fmaf(m.y, d.z, -(m.z * d.y))) - __builtin_fmaf(n.h1, az, n.h2 * ay);
-    const float sy = __builtin_fabsf(__builtin_fmaf(m.z, d.x, -(m.x * d.z))) - __builtin_fmaf(n.h2, ax, n.h0 * az);
-    const float sz = __builtin_fabsf(__builtin_fmaf(m.x, d.y, -(m.y * d.x))) - __builtin_fmaf(n.h0, ay, n.h1 * ax);
-    const float tmax = dotf(m, d) + __builtin_fmaf(n.h2, az, __builtin_fmaf(n.h1, ay, n.h0 * ax));
-    return (__builtin_fmaxf(__builtin_fmaxf(sx, sy), sz) > r.ecross) | (tmax < -r.ebehind);
+    // separating axes d x e_x, d x e_y, d x e_z: |m . axis| - sum_j h_j |axis_j|, four
+    // operations each (the absolute values are operand modifiers)
+    const float cx = __builtin_fabsf(__builtin_fmaf(m.y, d.z, -(m.z * d.y)));
+    const float cy = __builtin_fabsf(__builtin_fmaf(m.z, d.x, -(m.x * d.z)));
+    const float cz = __builtin_fabsf(__builtin_fmaf(m.x, d.y, -(m.y * d.x)));
+    const float sx = __builtin_fmaf(-n.h2, ay, __builtin_fmaf(-n.h1, az, cx));
+    const float sy = __builtin_fmaf(-n.h0, az, __builtin_fmaf(-n.h2, ax, cy));
+    const float sz = __builtin_fmaf(-n.h1, ax, __builtin_fmaf(-n.h0, ay, cz));
+    // largest ray parameter over the box, one chain of six
+    float tmax = m.x * d.x;
+    tmax = __builtin_fmaf(m.y, d.y, tmax);
+    tmax = __builtin_fmaf(m.z, d.z, tmax);
+    tmax = __builtin_fmaf(n.h0, ax, tmax);
+    tmax = __builtin_fmaf(n.h1, ay, tmax);
+    tmax = __builtin_fmaf(n.h2, az, tmax);
+    // one wave mask per condition: the lanes whose ray certainly misses the box
+    return __builtin_amdgcn_ballot_w64(__builtin_fmaxf(__builtin_fmaxf(sx, sy), sz) > r.ecross) |
+           __builtin_amdgcn_ballot_w64(tmax < -r.ebehind);
 }
 
 // Nearest hit over all objects (src/main.cc:37-47) through the tree.  Objects are met in
 // another order than the container's, so the reference's strict `t < nearest` in
 // container order becomes: smaller t wins, equal t goes to the smaller index.
+template <bool SPHERE>
+__device__ __forceinline__ void near_exact_candidate(cdata_t geom, int idx, V3 o, V3 d, double& nearest, int& cur) {
+    __asm__ volatile("" ::: "memory");
+    const DGeom g = load_geom(geom, idx);
+    double t;
+    const bool hit = test_collision<SPHERE>(g, o, d, t);
+    const bool closer = hit && (t < nearest || (t == nearest && idx < cur));
+    nearest = closer ? t : nearest;
+    cur = closer ? idx : cur;
+}
 template <bool COUNT>
 __device__ __forceinline__ void near_candidate(const FRec& gf, cdata_t geom, int idx, const FilterRay& fr, V3 o, V3 d,
                                                double& nearest, int& cur) {
-    if (!certain_miss(gf, fr)) {
-        __asm__ volatile("" ::: "memory");
-        const DGeom g = load_geom(geom, idx);
-        double t;
-        const bool hit = test_collision(g, o, d, t);
-        const bool closer = hit && (t < nearest || (t == nearest && idx < cur));
-        nearest = closer ? t : nearest;
-        cur = closer ? idx : cur;
-    }
+    if (!certain_miss(gf, fr)) near_exact_candidate<false>(geom, idx, o, d, nearest, cur);
+}
+template <bool COUNT>  // a leaf of the tree: always a sphere
+__device__ __forceinline__ void near_candidate(const FNode& nd, cdata_t geom, int idx, const FilterRay& fr, V3 o, V3 d,
+                                               double& nearest, int& cur) {
+    if (!certain_miss_sphere(nd.c0, nd.c1, nd.c2, nd.h0, fr)) near_exact_candidate<true>(geom, idx, o, d, nearest, cur);
 }
 template <bool COUNT, typename AT>
 __device__ __forceinline__ void find_nearest_tree(AT& a, cdata_t geom, V3 o, V3 d, double& nearest, int& cur,
@@ -523,33 +544,46 @@ __device__ __forceinline__ void find_nearest_tree(AT& a, cdata_t geom, V3 o, V3 
         const FRec gf = load_rec(pp);
         near_candidate<COUNT>(gf, geom, __float_as_int(pp[6]), fr, o, d, nearest, cur);
     }
-    const cfdata_t tree = (cfdata_t)(const float*)a.tree;
-    int i = 0;
-    while (i < a.n_nodes) {
-        const FNode nd = load_node(tree + 8 * i);
+    // The position in the tree is kept as a byte offset (one scalar add per step).
+    const RT_CONST char* tree = (const RT_CONST char*)(const char*)a.tree;
+    const uint32_t end = (uint32_t)a.n_nodes << 5;
+    uint32_t off = 0;
+    while (off < end) {
+        const FNode nd = load_node((cfdata_t)(tree + off));
         RT_ENTER(c_sph);  // (analysis builds: nodes visited)
+        off += 32u;
         if (nd.tag < 0) {  // leaf: the record is the sphere itself
-            near_candidate<COUNT>(leaf_rec(nd), geom, ~nd.tag, fr, o, d, nearest, cur);
-            ++i;
-        } else {
-            const bool maybe = !box_miss(nd, fr);
-            i = (__builtin_amdgcn_ballot_w64(maybe) != 0ull) ? i + 1 : nd.skip;
+            near_candidate<COUNT>(nd, geom, ~nd.tag, fr, o, d, nearest, cur);
+            continue;
         }
+        const unsigned long long walking = __builtin_amdgcn_ballot_w64(true);
+        off = ((walking & ~box_miss(nd, fr)) != 0ull) ? off : (uint32_t)nd.skip << 5;
     }
 }
 
 // Shadow feeler through the tree (src/objects.h:31-47): the reference stops at the first
 // occluder in container order, i.e. the occluder with the smallest index; `best` tracks it
 // and prunes every node that only holds larger indices.  Returns the index or INT_MAX.
+// `ruled_out` = the filter's answer; the rest is asked only of the lanes it leaves.
+template <bool SPHERE>
+__device__ __forceinline__ void feeler_exact_candidate(bool ruled_out, cdata_t geom, int idx, V3 ip, V3 fdir, int cur,
+                                                       int& best, double& pa, double& pb) {
+    if (!ruled_out & (idx != cur) & (idx < best)) {
+        __asm__ volatile("" ::: "memory");
+        const DGeom g = load_geom(geom, idx);
+        double na = pa, nb = pb;
+        const bool hit = collides<SPHERE>(g, ip, fdir, na, nb);
+        pa = na; pb = nb;
+        best = hit ? idx : best;
+    }
+}
 __device__ __forceinline__ void feeler_candidate(const FRec& gf, cdata_t geom, int idx, const FilterRay& fr, V3 ip, V3 fdir,
                                                  int cur, int& best, double& pa, double& pb) {
-    if (!certain_miss(gf, fr)) {
-        __asm__ volatile("" ::: "memory");
-        if (idx != cur && idx < best) {  // asked only of the lanes the filter leaves
-            const DGeom g = load_geom(geom, idx);
-            if (collides(g, ip, fdir, pa, pb)) best = idx;
-        }
-    }
+    feeler_exact_candidate<false>(certain_miss(gf, fr), geom, idx, ip, fdir, cur, best, pa, pb);
+}
+__device__ __forceinline__ void feeler_candidate(const FNode& nd, cdata_t geom, int idx, const FilterRay& fr, V3 ip, V3 fdir,
+                                                 int cur, int& best, double& pa, double& pb) {
+    feeler_exact_candidate<true>(certain_miss_sphere(nd.c0, nd.c1, nd.c2, nd.h0, fr), geom, idx, ip, fdir, cur, best, pa, pb);
 }
 template <typename AT>
 __device__ __forceinline__ int find_occluder_tree(AT& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur,
@@ -560,18 +594,21 @@ __device__ __forceinline__ int find_occluder_tree(AT& a, cdata_t geom, const Fil
         const FRec gf = load_rec(pp);
         feeler_candidate(gf, geom, __float_as_int(pp[6]), fr, ip, fdir, cur, best, pa, pb);
     }
-    const cfdata_t tree = (cfdata_t)(const float*)a.tree;
-    int i = 0;
-    while (i < a.n_nodes) {
-        const FNode nd = load_node(tree + 8 * i);
+    const RT_CONST char* tree = (const RT_CONST char*)(const char*)a.tree;
+    const uint32_t end = (uint32_t)a.n_nodes << 5;
+    uint32_t off = 0;
+    while (off < end) {
+        const FNode nd = load_node((cfdata_t)(tree + off));
         RT_ENTER(c_nodes);  // (analysis builds: nodes visited)
+        off += 32u;
         if (nd.tag < 0) {
-            feeler_candidate(leaf_rec(nd), geom, ~nd.tag, fr, ip, fdir, cur, best, pa, pb);
-            ++i;
-        } else {
-            const bool maybe = (nd.tag < best) && !box_miss(nd, fr);
-            i = (__builtin_amdgcn_ballot_w64(maybe) != 0ull) ? i + 1 : nd.skip;
+            feeler_candidate(nd, geom, ~nd.tag, fr, ip, fdir, cur, best, pa, pb);
+            continue;
         }
+        // entered when some lane still looks for an index below the node's smallest and
+        // its ray may touch the box
+        const unsigned long long open = __builtin_amdgcn_ballot_w64(nd.tag < best);
+        off = ((open & ~box_miss(nd, fr)) != 0ull) ? off : (uint32_t)nd.skip << 5;
     }
     return best;
 }
