@@ -81,6 +81,14 @@ typedef struct rt_light {
 #define RT_FLAG_TREE 4u       /* walk the sphere tree even for a small scene.  Without
                                  either flag the tree is used from 40 spheres on.  The
                                  results are identical bit for bit in both modes.        */
+#define RT_FLAG_PRUNE 8u      /* hit_id, masks and counters describe the ray tree that is
+                                 actually walked for the image: children whose path weight
+                                 is exactly zero (a material with reflectivity 0, or
+                                 transparency 0) are left out, as they always are when only
+                                 the image is asked for - the reference traces them and
+                                 multiplies what they return by zero (src/main.cc:107-112),
+                                 so the image is the same.  Without the flag these outputs
+                                 describe the reference's full ray tree.                  */
 
 /*
  * Per-render parameters: the values the reference hard-wires in Tracer()/main()

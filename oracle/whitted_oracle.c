@@ -79,6 +79,7 @@ typedef struct {
     const rt_light* lights; int n_lights;
     double bgr[3];
     int max_depth;
+    int prune;            /* RT_FLAG_PRUNE */
     /* instrumentation of the current pixel */
     uint32_t hit_mask[4], spawn_mask[4];
     int32_t hit_id;
@@ -193,8 +194,10 @@ static void trace_ray(octx* c, v3 o, v3 d, int depth, uint32_t node, double out[
 
     v3 vt = v3_div(d, fabs(v3_dot(d, n)));               /* src/main.cc:70 */
 
-    double refl[3];
-    {                                                    /* src/main.cc:74-81 */
+    /* RT_FLAG_PRUNE: a child under a material coefficient of exactly zero (as the device
+     * holds it, in float) is not traced; what it would return is multiplied by zero below. */
+    double refl[3] = {0.0, 0.0, 0.0};
+    if (!(c->prune && (float)obj->reflectivity == 0.0f)) { /* src/main.cc:74-81 */
         v3 rd = v3_unit(v3_add(vt, v3_scale(n, 2.0)));
         v3 ro = v3_add(ip, v3_scale(n, 1e-4));
         trace_ray(c, ro, v3_unit(rd), depth + 1, 2 * node, refl);
@@ -202,7 +205,7 @@ static void trace_ray(octx* c, v3 o, v3 d, int depth, uint32_t node, double out[
     double trans[3] = {0.0, 0.0, 0.0};
     {                                                    /* src/main.cc:84-97 */
         double k = (ri * ri) * v3_len2(vt) - v3_len2(v3_add(vt, n));
-        if (k > 0) {
+        if (k > 0 && !(c->prune && (float)obj->transparency == 0.0f)) {
             v3 td = v3_sub(v3_scale(v3_add(n, vt), 1.0 / sqrt(k)), n);
             td = v3_unit(td);
             v3 to = v3_sub(ip, v3_scale(n, 1e-4));
@@ -282,6 +285,7 @@ int oracle_render(const rt_prim* prims, int32_t n_prims, const rt_light* lights,
     rt_counters local;
     memset(&local, 0, sizeof local);
     c.cnt = ((p->flags & RT_FLAG_COUNTERS) && counters) ? &local : NULL;
+    c.prune = (p->flags & RT_FLAG_PRUNE) != 0;
 
     int64_t row = 0;                                     /* row index in strip order */
     for (int b = 0; b < p->band_count; ++b) {

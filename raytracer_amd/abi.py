@@ -22,6 +22,7 @@ RT_PRIM_SPHERE = 1
 RT_FLAG_COUNTERS = 1
 RT_FLAG_LINEAR = 2
 RT_FLAG_TREE = 4
+RT_FLAG_PRUNE = 8
 
 PRIM_DTYPE = np.dtype(
     [

@@ -213,6 +213,7 @@ int make_args(rt_ctx* ctx, const rt_params* p, rt::KArgs& a) {
     const double cmin = 0.5 * (a.pw < a.ph ? a.pw : a.ph);
     const double cmax = (0.5 * p->width + 1.0) * a.pw + (0.5 * p->height + 1.0) * a.ph;
     a.primary_in_range = (cmin >= 0x1p-370 && cmax <= 0x1p370) ? 1 : 0;
+    a.prune = (p->flags & RT_FLAG_PRUNE) ? 1 : 0;
     return RT_OK;
 }
 

@@ -99,6 +99,8 @@ struct KArgs {
     float scene_p1max;         // >= |centre|_1 of every sphere (filter bound)
     uint32_t band_magic;       // ceil(2^32 / band_rows): k / band_rows = mulhi(k, band_magic), k < 2^16
     int32_t primary_in_range;  // every primary ray's p1 passes the range guard of unit()
+    int32_t prune;             // ids, masks and counters describe the walk without the children of
+                               // weight zero (the image-only kernels always leave those out)
 };
 
 // The walk keeps at most one pending refraction child per tree level 2..max_depth-1, 3.5 KB

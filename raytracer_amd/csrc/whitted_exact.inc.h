@@ -151,10 +151,22 @@ __device__ __forceinline__ double div_mid(double n, double s, double y) {
 // that the wave runs either the short sequences or the plain operators, never both.
 __device__ __forceinline__ bool all_lanes(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
 
-// A numerator the unscaled division handles: zero, or at least `tiny` in magnitude.
-__device__ __forceinline__ bool mid_num(double v, double tiny) { return (__builtin_fabs(v) >= tiny) | (v == 0.0); }
-__device__ __forceinline__ bool mid_vec(V3 a, double tiny) {
-    return (int)mid_num(a.x, tiny) & (int)mid_num(a.y, tiny) & (int)mid_num(a.z, tiny);
+// The range guards look at exponent fields with integer operations (a double compare costs
+// as much as a double multiplication).  They are conservative: a value they turn away only
+// sends the wave through the plain operators, which return the same bits.
+// 2^lo <= v < 2^hi for a double v (false for negative values, NaN and infinity).
+__device__ __forceinline__ bool exp_within(double v, int lo, int hi) {
+    return (uint32_t)(__double2hiint(v) - ((1023 + lo) << 20)) < (uint32_t)((hi - lo) << 20);
+}
+// Every component at least 2^lo in magnitude.  (A zero component would be handled by the
+// unscaled division too, but telling zero from a denormal costs more than the rare wave
+// with a zero component loses on the plain operators.)
+__device__ __forceinline__ bool mid_vec(V3 a, int lo) {
+    const uint32_t ux = (uint32_t)__double2hiint(a.x) & 0x7fffffffu;
+    const uint32_t uy = (uint32_t)__double2hiint(a.y) & 0x7fffffffu;
+    const uint32_t uz = (uint32_t)__double2hiint(a.z) & 0x7fffffffu;
+    const uint32_t m = ux < uy ? ux : uy;
+    return (m < uz ? m : uz) >= (uint32_t)((1023 + lo) << 20);
 }
 
 // gmtl::normalize with the plain operators: length, then three divisions, skipped for a
@@ -168,7 +180,8 @@ __device__ __forceinline__ V3 unit_plain(V3 a) {
     }
     return a;
 }
-// The same for 2^-760 <= l2 = len2(a) <= 2^760 and components that are zero or >= 2^-380:
+// The same for 2^-760 <= l2 = len2(a) <= 2^760 and components that are zero or >= 2^-380
+// (the guards only admit the latter):
 // then len is in [2^-380, 2^380], |a_i| <= len (1 + 2^-52), every quotient is normal.
 __device__ __forceinline__ V3 unit_mid(V3 a, double l2) {
     const double len = sqrt_mid(l2);
@@ -178,7 +191,7 @@ __device__ __forceinline__ V3 unit_mid(V3 a, double l2) {
 __device__ __forceinline__ V3 unit(V3 a) {
     const double l2 = len2(a);
     V3 r;
-    if (all_lanes((l2 >= 0x1p-760) & (l2 <= 0x1p760) & mid_vec(a, 0x1p-380))) {
+    if (all_lanes(exp_within(l2, -760, 760) & mid_vec(a, -380))) {
         RT_MARK("resume");
         r = unit_mid(a, l2);
     } else {
@@ -195,7 +208,7 @@ __device__ __forceinline__ V3 unit(V3 a) {
 __device__ __forceinline__ V3 unit2(V3 a) {
     const double l2 = len2(a);
     V3 r;
-    if (all_lanes((l2 >= 0x1p-500) & (l2 <= 0x1p500) & mid_vec(a, 0x1p-250))) {
+    if (all_lanes(exp_within(l2, -500, 500) & mid_vec(a, -250))) {
         RT_MARK("resume");
         const V3 u = unit_mid(a, l2);
         r = unit_mid(u, len2(u));
@@ -210,7 +223,7 @@ __device__ __forceinline__ V3 unit2(V3 a) {
 // a / s, component by component, for |a_i| <= 2 max(s, 1) (both callers guarantee it).
 __device__ __forceinline__ V3 div3(V3 a, double s) {
     V3 r;
-    if (all_lanes((s >= 0x1p-380) & (s <= 0x1p380) & mid_vec(a, 0x1p-380))) {
+    if (all_lanes(exp_within(s, -380, 380) & mid_vec(a, -380))) {
         RT_MARK("resume");
         const double y = rcp_refined(s);
         r = mk(div_mid(a.x, s, y), div_mid(a.y, s, y), div_mid(a.z, s, y));
@@ -221,10 +234,24 @@ __device__ __forceinline__ V3 div3(V3 a, double s) {
     RT_MARK("resume");
     return r;
 }
+// sqrt(x) for the lanes with x >= 0; lanes with `unused` set may hold anything (their result
+// is not looked at) and do not keep the wave from the short sequence.
+__device__ __forceinline__ double sqrt_exact(double x, bool unused = false) {
+    double r;
+    if (all_lanes(exp_within(x, -760, 760) | unused)) {
+        RT_MARK("resume");
+        r = sqrt_mid(x);
+    } else {
+        RT_MARK("fallback");
+        r = __builtin_sqrt(x);
+    }
+    RT_MARK("resume");
+    return r;
+}
 // 1.0 / sqrt(x), both operations correctly rounded (src/main.cc:88).
 __device__ __forceinline__ double inv_sqrt_2r(double x) {
     double r;
-    if (all_lanes((x >= 0x1p-760) & (x <= 0x1p760))) {
+    if (all_lanes(exp_within(x, -760, 760))) {
         RT_MARK("resume");
         const double sx = sqrt_mid(x);
         const double y = rcp_refined(sx);
@@ -402,7 +429,7 @@ __device__ __forceinline__ bool test_collision(const DGeom& g, V3 o, V3 d, doubl
     const double d2 = dot(L, L) - tca * tca;
     const bool ok = !(tca < 0) & !(d2 > g.r2);
     if (ok) {
-        const double thc = __builtin_sqrt(g.r2 - d2);
+        const double thc = sqrt_exact(g.r2 - d2);
         const double t0 = tca - thc;
         t = (t0 < 0) ? tca + thc : t0;
     }
@@ -432,7 +459,7 @@ __device__ __forceinline__ bool collides(const DGeom& g, V3 o, V3 d, double& pa,
     return hit;
 }
 __device__ __forceinline__ double collision_value(double pa, double pb) {
-    const double thc = __builtin_sqrt(pb);   // NaN for a plane's -1, not used then
+    const double thc = sqrt_exact(pb, __double2hiint(pb) < 0);  // a plane's -1: not used
     const double t0 = pa - thc;
     const double ts = (t0 < 0) ? pa + thc : t0;
     return (pb < 0) ? pa : ts;
@@ -887,11 +914,16 @@ __device__ __forceinline__ void take_pixels(TileQueue& f, CArgs*& ap, bool& have
 
 // The primary ray of pixel (x, row k of the strip): src/main.cc:135-138,
 // src/view_frustum.h:37-46, src/common.h:27-31 (origin 0, direction returned).
+// Frame row of strip row k (increasing in k).
 template <typename AT>
-__device__ __forceinline__ V3 primary_direction(AT& a, int x, int k) {
+__device__ __forceinline__ int frame_row(AT& a, int k) {
     // band = k / band_rows without the division (KArgs::band_magic)
     const int band = (a.band_rows == 1) ? k : (int)__umulhi((uint32_t)k, a.band_magic);
-    const int y = (a.band_first + band * a.band_step) * a.band_rows + (k - band * a.band_rows);
+    return (a.band_first + band * a.band_step) * a.band_rows + (k - band * a.band_rows);
+}
+template <typename AT>
+__device__ __forceinline__ V3 primary_direction(AT& a, int x, int k) {
+    const int y = frame_row(a, k);
     const int xi = x - a.width / 2;
     const int yi = y - a.height / 2;
     const V3 v = mk((xi + 0.5) * a.pw, (yi + 0.5) * a.ph, 1.0) - mk(0.0, 0.0, 0.0);

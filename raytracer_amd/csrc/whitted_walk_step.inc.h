@@ -105,8 +105,16 @@
             // refraction test, src/main.cc:86-87
             const double kk = (ri * ri) * len2(vt) - len2(vt + n);
             const bool refr = kk > 0;
-            RT_EVENT(if (refr) ++c_refr);
             const float wr = w * kr, wt = w * kt;
+            // A child under a material coefficient of exactly zero has path weight zero and
+            // adds nothing to the pixel, whatever it hits (the reference traces it and
+            // multiplies by zero, src/main.cc:107-112): it is left out when only the image is
+            // asked for, or when the caller asks for the ray tree that is actually walked
+            // (KArgs::prune).
+            const bool prune = (MW == 0 && !COUNT) || a.prune;
+            const bool go_t = refr && !(prune && m_tr == 0.0f);
+            const bool go_r = !(prune && m_refl == 0.0f);
+            RT_EVENT(if (go_t) ++c_refr);
 
             if (level + 1 >= a.max_depth) {
                 RT_MARK("children_last");
@@ -116,7 +124,7 @@
             } else {
                 RT_MARK("children");
                 RT_ENTER(cnt[6]);
-                if (refr) {
+                if (go_t) {
                     RT_MARK("child_refraction");
                     // src/main.cc:88-93; Ray's constructor normalises again (src/common.h:24)
                     V3 td = (n + vt) * inv_sqrt_2r(kk) - n;
@@ -143,12 +151,14 @@
                 }
                 // src/main.cc:75-79
                 RT_MARK("child_reflection");
-                V3 rd = unit2(vt + n * 2.0);
-                o = ip + n * 1e-4;
-                d = rd;
-                w = wr;
-                node = 2 * node;
-                next_in_regs = true;
+                if (go_r) {
+                    V3 rd = unit2(vt + n * 2.0);
+                    o = ip + n * 1e-4;
+                    d = rd;
+                    w = wr;
+                    node = 2 * node;
+                    next_in_regs = true;
+                }
             }
         }
 

@@ -441,3 +441,35 @@ def test_zero_and_negative_radii(tracer, n_spheres):
     assert_parity(dev, ora, f"radii {n_spheres}")
     assert int(ora["counters"]["hits"]) > int(ora["counters"]["primary_hits"]) > 0
     tracer.upload_scene(prims, lights)
+
+
+@pytest.mark.parametrize("name", ["default", "random", "glass"])
+def test_pruned_ray_tree(tracer, name):
+    """RT_FLAG_PRUNE: ids, masks and counters of the walk without the children under a
+    material coefficient of zero equal the checker's in the same mode; the image is the one of
+    the full ray tree (those children are multiplied by zero), and image-only renders - which
+    always leave them out - give it too."""
+    if name == "default":
+        prims, lights = scenes.default_scene()
+    elif name == "random":
+        prims, lights = scenes.random_spheres_scene(30, 3, seed=0x9A1)
+        prims = prims.copy()
+        r, t = prims["reflectivity"].copy(), prims["transparency"].copy()
+        r[::3] = 0.0
+        t[1::4] = 0.0
+        prims["reflectivity"], prims["transparency"] = r, t
+    else:
+        prims, lights = scenes.glass_scene(8, 3)
+    p = abi.make_params(160, 96, 6)
+    full_dev, full_ora = _both(tracer, prims, lights, p)
+    assert_parity(full_dev, full_ora, f"full tree {name}")
+    pp = p.copy()
+    pp["flags"] = abi.RT_FLAG_PRUNE
+    dev = tracer.render(pp, want_counters=True)
+    ora = oracle_lib.render(prims, lights, pp, want_counters=True)
+    assert_parity(dev, ora, f"pruned tree {name}")
+    assert np.array_equal(dev["bgr"], full_dev["bgr"])
+    assert np.array_equal(ora["bgr"], full_ora["bgr"])
+    assert int(ora["counters"]["rays"]) <= int(full_ora["counters"]["rays"])
+    if name != "glass":
+        assert int(ora["counters"]["rays"]) < int(full_ora["counters"]["rays"])
