@@ -25,7 +25,12 @@ is the configuration the headline metric is quoted on: the reference's default s
 Rank 0 prints ONE JSON line.  value = rays of all frames of all ranks / wall time of the timed
 steps (max over ranks), with scene and buffers resident in HBM before the clock starts.  Rays =
 TraceRay invocations that pass the depth stop, counted by the kernel's counter variant in an
-untimed launch (and equal to the CPU checker's count).
+untimed launch (and equal to the CPU checker's count) - of the ray tree the timed kernel really
+walks: when only the image is asked for, a child under a material coefficient of exactly zero
+(reflectivity 0, transparency 0) is not traced, since the reference multiplies what it returns
+by zero; the counts are taken with RT_FLAG_PRUNE, which describes that walk.  The reference's
+full ray tree of the same frame is reported beside it (`reference_ray_tree`: its ray count and
+the rate that count would give), and `gpu_over_cpu` compares frames per second.
 
 roofline: the path is bound by the vector ALUs, not by MFMA or HBM, so `bound` is "valu" and
 `peak` is the gfx950 FP32 vector peak, 157.3 TFLOP/s.  achieved = algorithmic flops of one
@@ -87,6 +92,10 @@ WORKLOADS = {
     "default_8k_d5": (scenes.default_scene, 7680, 4320, 5),
 }
 EXTRA_WORKLOADS = ("spheres1024_4k_d5", "glass_4k_d8")
+# Event counts are taken of the ray tree the timed (image-only) kernel walks: children under a
+# material coefficient of zero are left out there (the reference traces them and multiplies by
+# zero), and counting them would credit the kernel with rays it never traces.
+COUNT_FLAGS = abi.RT_FLAG_COUNTERS | abi.RT_FLAG_PRUNE
 LATE_MIN_LIGHTS = 4    # kLateMinLights of the kernel launcher
 TREE_MIN_SPHERES = 40  # kTreeMinSpheres
 
@@ -240,6 +249,17 @@ class Timed:
         return [a.elapsed_time(b) for a, b in self.ev]
 
 
+def count_events(torch, tracer, params, flags, stream, scratch, d_cnt):
+    """One untimed launch of the counting kernel: the event counts of the render."""
+    pc = params.copy()
+    pc["flags"] = flags
+    d_cnt.zero_()
+    tracer.render_device(pc, stream.cuda_stream, scratch.data_ptr(), d_counters=d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    c = d_cnt.cpu().numpy().astype(np.uint64)
+    return {f: int(c[i]) for i, f in enumerate(abi.COUNTER_FIELDS)}
+
+
 def run_mode(mode, ctx):
     """Time `steps` steps of one mode.  Returns this rank's figures; collectives (barrier,
     max of the wall time, sum of the rays) are done here so that every rank takes part."""
@@ -261,13 +281,17 @@ def run_mode(mode, ctx):
     d_cnt = torch.zeros(8, dtype=torch.int64, device=device)
     scratch = torch.zeros((max(my_rows, 1), width, 3), dtype=torch.uint8, device=device)
     pc = my.copy()
-    pc["flags"] = abi.RT_FLAG_COUNTERS
+    pc["flags"] = COUNT_FLAGS
     tracer.render_device(pc, stream.cuda_stream, scratch.data_ptr(), d_counters=d_cnt.data_ptr())
     torch.cuda.synchronize()
     cnt_host = d_cnt.cpu().numpy().astype(np.uint64)
     counters = {f: int(cnt_host[i]) for i, f in enumerate(abi.COUNTER_FIELDS)}
     my_flops = algorithmic_flops(counters, my_rows * width)  # of ONE render of this rank
     my_rays = counters["rays"]
+    reference_rays = None
+    if mode == "single":
+        # the reference's full ray tree of the same frame, for comparison only
+        reference_rays = count_events(torch, tracer, my, abi.RT_FLAG_COUNTERS, stream, scratch, d_cnt)["rays"]
     renders_per_launch = 1
     gatherer = None
     frames_per_step = 1
@@ -395,6 +419,7 @@ def run_mode(mode, ctx):
         "flops_per_launch": my_flops * renders_per_launch,
         "fb_bytes": my_rows * renders_per_launch * width * 3,
         "batched": mode == "strips",
+        "reference_rays_per_frame": reference_rays,
     }
 
 
@@ -464,7 +489,7 @@ def extra_workload(name, torch, device, stream, local_rank, steps=3, warmup=1, c
     out = torch.zeros((height, width, 3), dtype=torch.uint8, device=device)
     d_cnt = torch.zeros(8, dtype=torch.int64, device=device)
     pc = base.copy()
-    pc["flags"] = abi.RT_FLAG_COUNTERS
+    pc["flags"] = COUNT_FLAGS
     tracer.render_device(pc, stream.cuda_stream, out.data_ptr(), d_counters=d_cnt.data_ptr())
     torch.cuda.synchronize()
     c = d_cnt.cpu().numpy().astype(np.uint64)
@@ -493,7 +518,9 @@ def extra_workload(name, torch, device, stream, local_rank, steps=3, warmup=1, c
         "roofline": roofline(prims, lights, depth, False, flops, kms, width * height * 3, name),
         "cpu_baseline": cpu_baseline(prims, lights, base, budget_s=cpu_budget_s),
     }
-    rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+    ref = count_events(torch, tracer, base, abi.RT_FLAG_COUNTERS, stream, out, d_cnt)["rays"]
+    rec["reference_ray_tree"] = {"rays_per_frame": ref, "Mrays_per_s_equivalent": ref * steps / elapsed / 1e6}
+    rec["gpu_over_cpu"] = rec["cpu_baseline"]["ms_per_frame"] / rec["ms_per_step"]  # frames per second
     tracer.close()
     return rec
 
@@ -577,6 +604,8 @@ def main():
                 "frames_per_step": head["frames_per_step"],
                 "rays_per_step": head["rays_total"] / max(args.steps, 1),
                 "band_rows": strips.DEFAULT_BAND_ROWS,
+                "rays_counted": "the ray tree the image-only kernel walks: children under a material coefficient "
+                                "of zero (reflectivity 0 / transparency 0) contribute zero and are not traced",
             },
             "roofline": roofline(prims, lights, depth, head["batched"], head["flops_per_launch"], head["kernel_ms"],
                                  head["fb_bytes"], args.workload, with_profile=(world == 1)),
@@ -590,10 +619,16 @@ def main():
                 for r in results
             }
         if world == 1:
+            ref = head["reference_rays_per_frame"]
+            line["config"]["reference_ray_tree"] = {
+                "rays_per_frame": ref,
+                "Mrays_per_s_equivalent": ref / (head["ms_per_step"] * 1e-3) / 1e6,
+            }
             cpu_ms = None
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(prims, lights, base)
-                line["config"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+                # frames per second (the CPU traces the reference's full ray tree)
+                line["config"]["gpu_over_cpu"] = line["cpu_baseline"]["ms_per_frame"] / line["ms_per_step"]
                 cpu_ms = line["cpu_baseline"]["ms_per_frame"]
             if not args.no_end_to_end:
                 line["end_to_end"] = end_to_end(tracer, prims, lights, base, cpu_ms)

@@ -24,7 +24,9 @@ builder, w, h, d = bench.WORKLOADS[name]
 prims, lights = builder()
 t = device.DeviceTracer(0)
 t.upload_scene(prims, lights)
-r = t.render(abi.make_params(w, h, d), want_ids=False, want_masks=False, want_counters=True)
+params = abi.make_params(w, h, d)
+params["flags"] = abi.RT_FLAG_PRUNE  # the walk of the image-only kernel, which the budget is about
+r = t.render(params, want_ids=False, want_masks=False, want_counters=True)
 c = [int(r["counters"][f]) for f in abi.COUNTER_FIELDS]
 waves = ((w + 7) // 8) * ((h + 7) // 8)
 n = len(prims)
