@@ -49,8 +49,10 @@
                 const V3 ns = unit(on_plane ? gq : (ip - gp));
                 n = on_plane ? gq : ns;
             }
-            const bool flipped = dot(n, d) > 0;  // src/main.cc:62-65
+            const double nd0 = dot(n, d);
+            const bool flipped = nd0 > 0;  // src/main.cc:62-65
             if (flipped) n = -n;
+            const double nd = flipped ? -nd0 : nd0;  // dot(n, d) of the flipped normal, the same bits
             const F3 nf = f3((float)n.x, (float)n.y, (float)n.z);
 
             // ---- Object::Shade, src/objects.h:20-65 ----
@@ -88,8 +90,17 @@
 
             // src/main.cc:70, 100-105
             RT_MARK("combine");
-            const V3 vt = div3(d, __builtin_fabs(dot(d, n)));
-            const float g1 = 1.0f + (float)dot(n, d);  // 1 - facing, facing = -dot(n, d)
+            // A child under a material coefficient of exactly zero has path weight zero and
+            // adds nothing to the pixel, whatever it hits (the reference traces it and
+            // multiplies by zero, src/main.cc:107-112): it is left out when only the image is
+            // asked for, or when the caller asks for the ray tree that is actually walked
+            // (KArgs::prune).
+            const bool prune = (MW == 0 && !COUNT) || a.prune;
+            const bool want_t = !(prune && m_tr == 0.0f);
+            const bool want_r = !(prune && m_refl == 0.0f);
+            V3 vt = mk(0.0, 0.0, 0.0);
+            if (__any(want_t | want_r)) vt = div3(d, __builtin_fabs(nd));  // dot(d, n): the same products and sums
+            const float g1 = 1.0f + (float)nd;  // 1 - facing, facing = -dot(n, d)
             const float fresnel = mix_tenth(g1 * g1 * g1, 1.0f);  // pow(1 - facing, 3), src/main.cc:101
             const float kt = (1.0f - fresnel) * m_tr;
             const float kr = (1.0f - kt) * m_refl;
@@ -102,24 +113,18 @@
             cg = __builtin_fmaf(wk, __builtin_fmaf(bgr.y, amb, sg), cg);
             cb = __builtin_fmaf(wk, __builtin_fmaf(bgr.z, amb, sb), cb);
 
-            // refraction test, src/main.cc:86-87
-            const double kk = (ri * ri) * len2(vt) - len2(vt + n);
-            const bool refr = kk > 0;
+            // refraction test, src/main.cc:86-87 (asked only where a refraction child matters)
+            double kk = 0.0;
+            if (__any(want_t)) kk = (ri * ri) * len2(vt) - len2(vt + n);
             const float wr = w * kr, wt = w * kt;
-            // A child under a material coefficient of exactly zero has path weight zero and
-            // adds nothing to the pixel, whatever it hits (the reference traces it and
-            // multiplies by zero, src/main.cc:107-112): it is left out when only the image is
-            // asked for, or when the caller asks for the ray tree that is actually walked
-            // (KArgs::prune).
-            const bool prune = (MW == 0 && !COUNT) || a.prune;
-            const bool go_t = refr && !(prune && m_tr == 0.0f);
-            const bool go_r = !(prune && m_refl == 0.0f);
+            const bool go_t = want_t && kk > 0;
+            const bool go_r = want_r;
             RT_EVENT(if (go_t) ++c_refr);
 
             if (level + 1 >= a.max_depth) {
                 RT_MARK("children_last");
                 // both children stop at the depth limit and return the background
-                const float ws = refr ? (wr + wt) : wr;
+                const float ws = go_t ? (wr + wt) : wr;  // (a child that is left out has weight zero)
                 cr = __builtin_fmaf(ws, bgr.x, cr); cg = __builtin_fmaf(ws, bgr.y, cg); cb = __builtin_fmaf(ws, bgr.z, cb);
             } else {
                 RT_MARK("children");
