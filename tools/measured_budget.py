@@ -32,7 +32,10 @@ KERNEL = "whitted_kernel<0, false, false, false, false>"
 def run():
     import torch
 
-    from raytracer_amd import abi, scenes
+    from raytracer_amd import abi, device, scenes
+
+    if os.environ.get("RT_LIB_OVERRIDE"):  # another build of the library, for comparisons on one box
+        device.LIB_PATH = os.path.abspath(os.environ["RT_LIB_OVERRIDE"])
     from raytracer_amd.device import DeviceTracer
 
     prims, lights = scenes.default_scene()
