@@ -125,6 +125,17 @@ __host__ __device__ inline int stack_global_entries(int max_depth) {
 inline size_t stack_lds_bytes(int max_depth) {
     return (size_t)kWavesPerBlock * stack_lds_entries(max_depth) * kStackFields * 64 * sizeof(double);
 }
+// Launches with one wave per tile (max_depth <= 3 + kStackLdsEntries, container-order loops)
+// keep no entry in registers: entries 0..kStackLdsEntries-1 in LDS, the last one - reached
+// only by a refraction child at the deepest level that has children - in the lane's private
+// memory.
+__host__ __device__ inline int tile_stack_lds_entries(int max_depth) {
+    const int e = stack_entries(max_depth);
+    return e > kStackLdsEntries ? kStackLdsEntries : e;
+}
+inline size_t tile_stack_lds_bytes(int max_depth) {
+    return (size_t)kWavesPerBlock * tile_stack_lds_entries(max_depth) * kStackFields * 64 * sizeof(double);
+}
 // Deep-stack launches: grid size and workspace.  The workspace starts with a 256-byte
 // header whose first word is the tile queue; the waves' regions follow.
 constexpr int kDeepMaxBlocks = 1024;      // 256 CUs x 4 resident blocks of 4 waves

@@ -969,7 +969,12 @@ __device__ __forceinline__ void trace_tile(AT& a, const int x, const int k, bool
     float w = 1.0f;  // product of the reflection/refraction coefficients on the path (colour)
     uint32_t node = 1;
     int sp = 0;
-    double bottom[kStackFields] = {0, 0, 0, 0, 0, 0, 0};  // stack entry 0, in registers
+    // The stack (whitted_device.h: tile launches): entries 0 and 1 in LDS, the last one in
+    // the lane's private memory - the pointer is made opaque so that it stays there instead of
+    // taking fourteen registers for a value that is rarely used.
+    double last_entry_store[kStackFields];
+    double* last_entry = last_entry_store;
+    __asm__ volatile("" : "+v"(last_entry));
     float cr = 0.0f, cg = 0.0f, cb = 0.0f;
     int32_t first_hit = -1;
     uint32_t hmask[MW > 0 ? MW : 1] = {0};
@@ -978,9 +983,11 @@ __device__ __forceinline__ void trace_tile(AT& a, const int x, const int k, bool
     RT_MARK("prologue");
 
 #define RT_WALK_FINISHED have = false
+#define RT_STEP_TILE_STACK 1
     while (have) {
 #include "whitted_walk_step.inc.h"
     }
+#undef RT_STEP_TILE_STACK
 #undef RT_WALK_FINISHED
 
     RT_MARK("epilogue");

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     const KArgs& a = a_;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* stk = lds_stack + (size_t)wave * stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
+    double* stk = lds_stack + (size_t)wave * ((DEEP || TREE) ? stack_lds_entries(a.max_depth) : tile_stack_lds_entries(a.max_depth)) * kStackFields * 64 + lane;
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (DEEP || TREE) {
         double* gstk = DEEP ? wave_gstack(a, (size_t)blockIdx.x * kWavesPerBlock + wave) : nullptr;
@@ -93,7 +93,7 @@ template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
 static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t stream) {
     const int bx = (a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     if (bx <= 0 || a.tiles_y <= 0) return hipSuccess;
-    const size_t lds = stack_lds_bytes(a.max_depth);
+    const size_t lds = (DEEP || TREE) ? stack_lds_bytes(a.max_depth) : tile_stack_lds_bytes(a.max_depth);
     if (DEEP || TREE) {
         if (deep_blocks < 1 || deep_blocks > kDeepMaxBlocks || !a.tile_queue || (DEEP && !a.gstack)) return hipErrorInvalidValue;
         hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE>), dim3(deep_blocks), dim3(64 * kWavesPerBlock), lds, stream, a);
@@ -130,7 +130,7 @@ void whitted_batch_kernel(KBatch, int n) {
     } else {
         CArgs& a = b.a[blockIdx.z];
         if ((int)blockIdx.y >= a.tiles_y || (int)(blockIdx.x * kWavesPerBlock) >= a.tiles_x) return;
-        double* stk = lds_stack + (size_t)wave * stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
+        double* stk = lds_stack + (size_t)wave * tile_stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
         const int tx = blockIdx.x * kWavesPerBlock + wave;
         const int ty = blockIdx.y;
         const int x = tx * kTile + (lane & 7);
@@ -148,9 +148,9 @@ hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, int deep_bloc
         depth = max(depth, a.max_depth);
     }
     if (n <= 0 || bx <= 0 || by <= 0) return hipSuccess;
-    const size_t lds = stack_lds_bytes(depth);
     const bool deep = stack_global_entries(depth) > 0;
     const bool queue = deep || tree;
+    const size_t lds = queue ? stack_lds_bytes(depth) : tile_stack_lds_bytes(depth);
     if (queue && (deep_blocks < 1 || deep_blocks > kDeepMaxBlocks || !b.a[0].tile_queue || (deep && !b.a[0].gstack)))
         return hipErrorInvalidValue;
     const dim3 grid = queue ? dim3(deep_blocks) : dim3(bx, by, n);
