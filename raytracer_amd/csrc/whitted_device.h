@@ -104,7 +104,8 @@ struct KArgs {
 };
 
 // The walk keeps at most one pending refraction child per tree level 2..max_depth-1, 3.5 KB
-// per wave and entry.  Entry 0 (pushed by the primary hit) lives in registers, the next
+// per wave and entry.  Launches with a fixed grid (the tile queue): entry 0 (pushed by the
+// primary hit) lives in registers, the next
 // kStackLdsEntries in LDS (what bounds the number of resident waves: 7 KB per wave keeps
 // four waves per SIMD), deeper ones in a global-memory workspace, written and read back by
 // the same wave while it is still in the L2.  A launch that needs the workspace (max_depth
