@@ -145,8 +145,8 @@ int stream_workspace(rt_ctx* ctx, void* stream, bool deep, void** out) {
 // `stream`; returns the grid size of the launch (0 when the depth needs no workspace).
 int attach_workspace(rt_ctx* ctx, rt::KArgs* args, int n, long long tiles, int max_depth, void* ws, hipStream_t stream,
                      int* deep_blocks) {
-    *deep_blocks = rt::deep_grid_blocks(ctx->n_cus, tiles);
     const bool deep = rt::stack_global_entries(max_depth) > 0;
+    *deep_blocks = rt::deep_grid_blocks(ctx->n_cus, tiles, deep);
     for (int i = 0; i < n; ++i) {
         args[i].tile_queue = static_cast<unsigned int*>(ws);
         args[i].gstack = deep ? reinterpret_cast<double*>(static_cast<char*>(ws) + rt::kWorkspaceHeader) : nullptr;

@@ -145,9 +145,14 @@ constexpr size_t kWorkspaceHeader = 256;
 constexpr size_t kDeepRegionBytes =       // per wave, at RT_MAX_DEPTH
     (size_t)(RT_MAX_DEPTH - 3 - kStackLdsEntries) * kStackFields * 64 * sizeof(double);
 constexpr size_t kWorkspaceMaxBytes = kWorkspaceHeader + (size_t)kDeepMaxBlocks * kWavesPerBlock * kDeepRegionBytes;
-inline int deep_grid_blocks(int n_cus, long long tiles) {
-    long long g = (long long)n_cus * kDeepBlocksPerCu;
-    if (g > kDeepMaxBlocks) g = kDeepMaxBlocks;
+// Launches with a queue but without the global stack (sphere-tree scenes at max_depth <= 5)
+// fit five waves per SIMD: five blocks per CU.
+constexpr int kQueueBlocksPerCu = 5;
+constexpr int kQueueMaxBlocks = 256 * kQueueBlocksPerCu;
+inline int deep_grid_blocks(int n_cus, long long tiles, bool deep = true) {
+    long long g = (long long)n_cus * (deep ? kDeepBlocksPerCu : kQueueBlocksPerCu);
+    const long long cap = deep ? kDeepMaxBlocks : kQueueMaxBlocks;
+    if (g > cap) g = cap;
     const long long need = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     if (g > need) g = need;
     return (int)(g < 1 ? 1 : g);

@@ -982,12 +982,13 @@ __device__ __forceinline__ void trace_tile(AT& a, const int x, const int k, bool
     RT_WALK_COUNTERS
     RT_MARK("prologue");
 
+    double bottom[kStackFields];  // (not used by this layout)
 #define RT_WALK_FINISHED have = false
-#define RT_STEP_TILE_STACK 1
+#define RT_STACK_IN_LDS true
     while (have) {
 #include "whitted_walk_step.inc.h"
     }
-#undef RT_STEP_TILE_STACK
+#undef RT_STACK_IN_LDS
 #undef RT_WALK_FINISHED
 
     RT_MARK("epilogue");
@@ -1005,7 +1006,13 @@ __device__ __forceinline__ void trace_queue(TileQueue& feed, double* stk, double
     float w = 1.0f;
     uint32_t node = 1;
     int sp = 0;
+    // The stack (whitted_device.h): with the global part (DEEP) entry 0 in registers, the next
+    // two in LDS, the rest in the workspace; without it as in trace_tile - entries 0 and 1 in
+    // LDS, the last one in the lane's private memory.
     double bottom[kStackFields] = {0, 0, 0, 0, 0, 0, 0};
+    double last_entry_store[kStackFields];
+    double* last_entry = last_entry_store;
+    __asm__ volatile("" : "+v"(last_entry));
     float cr = 0.0f, cg = 0.0f, cb = 0.0f;
     int32_t first_hit = -1;
     uint32_t hmask[MW > 0 ? MW : 1] = {0};
@@ -1036,6 +1043,7 @@ __device__ __forceinline__ void trace_queue(TileQueue& feed, double* stk, double
         store_pixel<MW>(a, x, k, cr, cg, cb, first_hit, hmask, smask);      \
         have = false;                                                        \
     } while (0)
+#define RT_STACK_IN_LDS (!DEEP)
     for (;;) {
         RT_MARK("refill");
         take_pixels(feed, ap, have, begin_pixel);
@@ -1050,6 +1058,7 @@ __device__ __forceinline__ void trace_queue(TileQueue& feed, double* stk, double
 #include "whitted_walk_step.inc.h"
         }
     }
+#undef RT_STACK_IN_LDS
 #undef RT_WALK_FINISHED
 }
 #undef RT_EVENT

@@ -64,12 +64,12 @@ __device__ __forceinline__ double* wave_gstack(AT& a, size_t w) {
 // Without the deep stack the grid holds one wave per 8x8 tile of the strip; with it the grid
 // is fixed and its waves take pixels from the tile queue (TileQueue).
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? ((DEEP || TREE) ? 4 : RT_IMAGE_WAVES) : 3, (MW == 0 && !COUNT && !DEEP && !TREE && RT_IMAGE_WAVES > 4) ? RT_IMAGE_WAVES : 4))) void whitted_kernel(KArgs a_) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? (DEEP ? 4 : RT_IMAGE_WAVES) : 3, (MW == 0 && !COUNT && !DEEP && RT_IMAGE_WAVES > 4) ? RT_IMAGE_WAVES : 4))) void whitted_kernel(KArgs a_) {
     extern __shared__ double lds_stack[];
     const KArgs& a = a_;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* stk = lds_stack + (size_t)wave * ((DEEP || TREE) ? stack_lds_entries(a.max_depth) : tile_stack_lds_entries(a.max_depth)) * kStackFields * 64 + lane;
+    double* stk = lds_stack + (size_t)wave * (DEEP ? stack_lds_entries(a.max_depth) : tile_stack_lds_entries(a.max_depth)) * kStackFields * 64 + lane;
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (DEEP || TREE) {
         double* gstk = DEEP ? wave_gstack(a, (size_t)blockIdx.x * kWavesPerBlock + wave) : nullptr;
@@ -93,9 +93,9 @@ template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
 static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t stream) {
     const int bx = (a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     if (bx <= 0 || a.tiles_y <= 0) return hipSuccess;
-    const size_t lds = (DEEP || TREE) ? stack_lds_bytes(a.max_depth) : tile_stack_lds_bytes(a.max_depth);
+    const size_t lds = DEEP ? stack_lds_bytes(a.max_depth) : tile_stack_lds_bytes(a.max_depth);
     if (DEEP || TREE) {
-        if (deep_blocks < 1 || deep_blocks > kDeepMaxBlocks || !a.tile_queue || (DEEP && !a.gstack)) return hipErrorInvalidValue;
+        if (deep_blocks < 1 || deep_blocks > (DEEP ? kDeepMaxBlocks : kQueueMaxBlocks) || !a.tile_queue || (DEEP && !a.gstack)) return hipErrorInvalidValue;
         hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE>), dim3(deep_blocks), dim3(64 * kWavesPerBlock), lds, stream, a);
     } else {
         hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
@@ -108,7 +108,7 @@ static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t strea
 // render, the grid is sized for the largest one and blocks outside a smaller one return at
 // once; with it the renders' tiles form one queue (tile_end = running totals).
 template <bool TREE, bool DEEP, bool LATE>
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(DEEP ? 4 : RT_IMAGE_WAVES, DEEP ? 4 : RT_IMAGE_WAVES)))
 void whitted_batch_kernel(KBatch, int n) {
     extern __shared__ double lds_stack[];
     const RT_CONST KBatch& b = *(const RT_CONST KBatch*)__builtin_amdgcn_kernarg_segment_ptr();  // the first argument
@@ -119,7 +119,7 @@ void whitted_batch_kernel(KBatch, int n) {
         // every render's stack entries sit at the offsets of the deepest render of the launch
         int depth = 0;
         for (int i = 0; i < n; ++i) depth = max(depth, b.a[i].max_depth);
-        double* stk = lds_stack + (size_t)wave * stack_lds_entries(depth) * kStackFields * 64 + lane;
+        double* stk = lds_stack + (size_t)wave * (DEEP ? stack_lds_entries(depth) : tile_stack_lds_entries(depth)) * kStackFields * 64 + lane;
         double* gstk = DEEP ? wave_gstack(b.a[0], (size_t)blockIdx.x * kWavesPerBlock + wave) : nullptr;
         TileQueue feed;
         feed.renders = b.a;
@@ -150,8 +150,8 @@ hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, int deep_bloc
     if (n <= 0 || bx <= 0 || by <= 0) return hipSuccess;
     const bool deep = stack_global_entries(depth) > 0;
     const bool queue = deep || tree;
-    const size_t lds = queue ? stack_lds_bytes(depth) : tile_stack_lds_bytes(depth);
-    if (queue && (deep_blocks < 1 || deep_blocks > kDeepMaxBlocks || !b.a[0].tile_queue || (deep && !b.a[0].gstack)))
+    const size_t lds = deep ? stack_lds_bytes(depth) : tile_stack_lds_bytes(depth);
+    if (queue && (deep_blocks < 1 || deep_blocks > (deep ? kDeepMaxBlocks : kQueueMaxBlocks) || !b.a[0].tile_queue || (deep && !b.a[0].gstack)))
         return hipErrorInvalidValue;
     const dim3 grid = queue ? dim3(deep_blocks) : dim3(bx, by, n);
     const dim3 block(64 * kWavesPerBlock);

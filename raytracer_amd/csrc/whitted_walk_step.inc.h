@@ -138,17 +138,16 @@
                     // the weight (float) and the node number share the last field
                     const double ent[kStackFields] = {to.x, to.y, to.z, td.x, td.y, td.z,
                                                       __hiloint2double((int)(2 * node + 1), __float_as_int(wt))};
-#ifdef RT_STEP_TILE_STACK
-                    if (sp < kStackLdsEntries) {
-                        double* e = stk + (size_t)sp * kStackFields * 64;
+                    if (RT_STACK_IN_LDS) {  // (a constant of the including function)
+                        if (sp < kStackLdsEntries) {
+                            double* e = stk + (size_t)sp * kStackFields * 64;
 #pragma unroll
-                        for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
-                    } else {
+                            for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
+                        } else {
 #pragma unroll
-                        for (int f = 0; f < kStackFields; ++f) last_entry[f] = ent[f];
-                    }
-#else
-                    if (sp == 0) {
+                            for (int f = 0; f < kStackFields; ++f) last_entry[f] = ent[f];
+                        }
+                    } else if (sp == 0) {
 #pragma unroll
                         for (int f = 0; f < kStackFields; ++f) bottom[f] = ent[f];
                     } else {
@@ -162,7 +161,6 @@
                             for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
                         }
                     }
-#endif
                     ++sp;
                 }
                 // src/main.cc:75-79
@@ -183,17 +181,16 @@
             if (sp > 0) {
                 --sp;
                 double ent[kStackFields];
-#ifdef RT_STEP_TILE_STACK
-                if (sp < kStackLdsEntries) {
-                    const double* e = stk + (size_t)sp * kStackFields * 64;
+                if (RT_STACK_IN_LDS) {
+                    if (sp < kStackLdsEntries) {
+                        const double* e = stk + (size_t)sp * kStackFields * 64;
 #pragma unroll
-                    for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
-                } else {
+                        for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
+                    } else {
 #pragma unroll
-                    for (int f = 0; f < kStackFields; ++f) ent[f] = last_entry[f];
-                }
-#else
-                if (sp == 0) {
+                        for (int f = 0; f < kStackFields; ++f) ent[f] = last_entry[f];
+                    }
+                } else if (sp == 0) {
 #pragma unroll
                     for (int f = 0; f < kStackFields; ++f) ent[f] = bottom[f];
                 } else {
@@ -207,7 +204,6 @@
                         for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
                     }
                 }
-#endif
                 o = mk(ent[0], ent[1], ent[2]);
                 d = mk(ent[3], ent[4], ent[5]);
                 w = __int_as_float(__double2loint(ent[6]));
