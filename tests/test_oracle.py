@@ -162,3 +162,31 @@ def test_depth_limit_and_background():
     assert (r2["bgr"][sky] == want).all()
     with pytest.raises(ValueError):
         oracle_lib.render(prims, lights, abi.make_params(32, 32, 9))
+
+
+def test_pruned_ray_tree_is_a_subtree_with_the_same_image():
+    """RT_FLAG_PRUNE (the checker's side of it): leaving out the children under a material
+    coefficient of zero changes no pixel (they are multiplied by zero), keeps the first hit,
+    and only ever clears bits of the hit and spawn masks; on the default scene, whose floor
+    reflects and transmits nothing, it removes about half of the rays."""
+    prims, lights = scenes.default_scene()
+    p = abi.make_params(96, 64, 5)
+    full = oracle_lib.render(prims, lights, p, want_counters=True)
+    pp = p.copy()
+    pp["flags"] = abi.RT_FLAG_PRUNE
+    cut = oracle_lib.render(prims, lights, pp, want_counters=True)
+    assert np.array_equal(cut["bgr"], full["bgr"])
+    assert np.array_equal(cut["hit_id"], full["hit_id"])
+    for k in ("hit_mask", "spawn_mask"):
+        assert not np.any(cut[k] & ~full[k]), k
+    assert int(cut["counters"]["primary_hits"]) == int(full["counters"]["primary_hits"])
+    assert 0.4 < int(cut["counters"]["rays"]) / int(full["counters"]["rays"]) < 0.7
+    # a scene without such materials is walked in full
+    glass, gl = scenes.glass_scene(4, 2)
+    glass = glass[1:]  # without the floor
+    a = oracle_lib.render(glass, gl, abi.make_params(48, 32, 4), want_counters=True)
+    q = abi.make_params(48, 32, 4)
+    q["flags"] = abi.RT_FLAG_PRUNE
+    b = oracle_lib.render(glass, gl, q, want_counters=True)
+    for f in a["counters"].dtype.names:
+        assert int(a["counters"][f]) == int(b["counters"][f]), f
