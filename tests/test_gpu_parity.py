@@ -473,3 +473,32 @@ def test_pruned_ray_tree(tracer, name):
     assert int(ora["counters"]["rays"]) <= int(full_ora["counters"]["rays"])
     if name != "glass":
         assert int(ora["counters"]["rays"]) < int(full_ora["counters"]["rays"])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_materials_depths_and_modes(tracer, seed):
+    """Random small scenes whose materials mix zero and non-zero reflectivity / transparency,
+    at a random depth, in both object-loop modes: full ray tree and pruned ray tree against the
+    checker in the same mode, and the image-only render (which prunes) against the full image."""
+    rng = np.random.default_rng(0xF0221 + seed)
+    n = int(rng.integers(2, 14))
+    prims, lights = scenes.random_spheres_scene(n, int(rng.integers(0, 5)), seed=0x1000 + seed)
+    prims = prims.copy()
+    r, t = prims["reflectivity"].copy(), prims["transparency"].copy()
+    r[rng.random(len(r)) < 0.4] = 0.0
+    t[rng.random(len(t)) < 0.4] = 0.0
+    t[rng.random(len(t)) < 0.1] = 1.0
+    prims["reflectivity"], prims["transparency"] = r, t
+    depth = int(rng.integers(2, 9))
+    w, h = int(rng.integers(20, 90)), int(rng.integers(20, 70))
+    for mode in (abi.RT_FLAG_LINEAR, abi.RT_FLAG_TREE):
+        p = abi.make_params(w, h, depth)
+        p["flags"] = mode
+        dev, ora = _both(tracer, prims, lights, p)
+        assert_parity(dev, ora, f"fuzz {seed} depth {depth} mode {mode} full")
+        pp = p.copy()
+        pp["flags"] = mode | abi.RT_FLAG_PRUNE
+        cut = tracer.render(pp, want_counters=True)
+        cut_ora = oracle_lib.render(prims, lights, pp, want_counters=True)
+        assert_parity(cut, cut_ora, f"fuzz {seed} depth {depth} mode {mode} pruned")
+        assert np.array_equal(cut["bgr"], dev["bgr"])

@@ -23,10 +23,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-LADDER = ["background", "depth2_dark", "depth2", "depth3", "depth4", "depth5"]
-N = 5
+SCENE = os.environ.get("RT_BUDGET_SCENE", "default")  # "glass": the same ladder on the glass scene, up to depth 8
+if SCENE == "glass":
+    LADDER = ["background", "depth2_dark", "depth2", "depth3", "depth5", "depth8"]
+    N = 3
+    KERNEL = "whitted_kernel<0, false, false, "   # depth <= 5: <.., false, true>, depth 8: <.., true, true>
+else:
+    LADDER = ["background", "depth2_dark", "depth2", "depth3", "depth4", "depth5"]
+    N = 5
+    KERNEL = "whitted_kernel<0, false, false, false, false>"
 W, H = 3840, 2160
-KERNEL = "whitted_kernel<0, false, false, false, false>"
 
 
 def run():
@@ -38,7 +44,7 @@ def run():
         device.LIB_PATH = os.path.abspath(os.environ["RT_LIB_OVERRIDE"])
     from raytracer_amd.device import DeviceTracer
 
-    prims, lights = scenes.default_scene()
+    prims, lights = scenes.glass_scene() if SCENE == "glass" else scenes.default_scene()
     far = prims.copy()
     pp, qq = far["p"].copy(), far["q"].copy()
     pp[:, 2] -= 1000.0
@@ -52,6 +58,7 @@ def run():
         "depth3": (prims, lights, 3),
         "depth4": (prims, lights, 4),
         "depth5": (prims, lights, 5),
+        "depth8": (prims, lights, 8),
     }
     t = DeviceTracer(0)
     out = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
@@ -108,16 +115,13 @@ def report(pmc_dir, trace_dir, events_json=None):
               f"{c.get('SQ_INSTS_VALU', 0) / waves:11.1f}{e.get('rays', 0):12d}{e.get('hits', 0):11d}{e.get('feelers', 0):11d}")
     print()
     print("Differences (what each part of the work costs in the headline frame):")
-    total_v, total_t = counters["depth5"]["SQ_INSTS_VALU"], times["depth5"]
+    total_v, total_t = counters[LADDER[-1]]["SQ_INSTS_VALU"], times[LADDER[-1]]
     ev = lambda n, k: events.get(n, {}).get(k, 0)
     steps = [
         ("primary rays + one nearest-hit pass + store, all pixels", None, "background", "rays"),
         ("primary hits: normal, own colour, child set-up", "background", "depth2_dark", "hits"),
         ("shadow feelers of the primary hits", "depth2_dark", "depth2", "feelers"),
-        ("tree level 2: rays, hits, feelers", "depth2", "depth3", "rays"),
-        ("tree level 3", "depth3", "depth4", "rays"),
-        ("tree level 4", "depth4", "depth5", "rays"),
-    ]
+    ] + [(f"tree levels up to {b[5:]} (rays, hits, feelers)", a, b, "rays") for a, b in zip(LADDER[2:-1], LADDER[3:])]
     print(f"{'part':58s}{'VALU insts':>13s}{'share':>8s}{'us':>8s}{'share':>8s}{'events':>11s}{'VALU/event/64':>15s}")
     for label, a, b, key in steps:
         dv = counters[b]["SQ_INSTS_VALU"] - (counters[a]["SQ_INSTS_VALU"] if a else 0.0)
