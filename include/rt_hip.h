@@ -154,7 +154,7 @@ void rt_destroy(rt_ctx* ctx);
 /*
  * Device memory a context holds besides the scene and the staging buffers of rt_render
  * (which grow to the largest frame rendered): renders with max_depth > 5 keep part of their
- * ray stacks in a workspace of 42 MiB (256 CUs), one per stream such a render was enqueued
+ * ray stacks in a workspace of 52.5 MiB (256 CUs), one per stream such a render was enqueued
  * on, allocated at the first such render on that stream; renders of scenes that use the
  * sphere tree (40 spheres or more) at smaller depths need 256 bytes per stream the same way.
  * Renders of smaller scenes at max_depth <= 5 allocate nothing.  rt_trim() waits for the
@@ -222,7 +222,7 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
  * rt_render_device for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc): same arguments, same
  * results, but a render that needs a workspace (max_depth > 5, or a scene with the sphere
- * tree) keeps it in an array built into the library (42 MiB + 256 bytes per GPU the library runs on, held until the process
+ * tree) keeps it in an array built into the library (52.5 MiB + 256 bytes per GPU the library runs on, held until the process
  * ends) instead of one allocated per stream, so the call never allocates or frees.  The
  * array holds the stacks of the largest launch grid at max_depth 8, the library's limit;
  * a larger max_depth is refused with RT_ERR_ARG like everywhere else, and the frame size

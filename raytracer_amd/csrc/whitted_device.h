@@ -107,11 +107,11 @@ struct KArgs {
 // per wave and entry.  Launches with a fixed grid (the tile queue): entry 0 (pushed by the
 // primary hit) lives in registers, the next
 // kStackLdsEntries in LDS (what bounds the number of resident waves: 7 KB per wave keeps
-// four waves per SIMD), deeper ones in a global-memory workspace, written and read back by
+// five waves per SIMD), deeper ones in a global-memory workspace, written and read back by
 // the same wave while it is still in the L2.  A launch that needs the workspace (max_depth
 // > 5) is a fixed grid of at most kDeepMaxBlocks blocks whose waves take 8x8 tiles from a
 // queue (one atomic add per tile) until it is empty, so the workspace holds one region per
-// wave of that grid whatever the frame size: 42 MiB for the full grid at max_depth 8.
+// wave of that grid whatever the frame size: 52.5 MiB for the full grid at max_depth 8.
 constexpr int kStackLdsEntries = 2;
 __host__ __device__ inline int stack_entries(int max_depth) { return max_depth > 2 ? max_depth - 2 : 0; }
 __host__ __device__ inline int stack_lds_entries(int max_depth) {
@@ -139,8 +139,8 @@ inline size_t tile_stack_lds_bytes(int max_depth) {
 }
 // Deep-stack launches: grid size and workspace.  The workspace starts with a 256-byte
 // header whose first word is the tile queue; the waves' regions follow.
-constexpr int kDeepMaxBlocks = 1024;      // 256 CUs x 4 resident blocks of 4 waves
-constexpr int kDeepBlocksPerCu = 4;
+constexpr int kDeepMaxBlocks = 1280;      // 256 CUs x 5 resident blocks of 4 waves
+constexpr int kDeepBlocksPerCu = 5;
 constexpr size_t kWorkspaceHeader = 256;
 constexpr size_t kDeepRegionBytes =       // per wave, at RT_MAX_DEPTH
     (size_t)(RT_MAX_DEPTH - 3 - kStackLdsEntries) * kStackFields * 64 * sizeof(double);

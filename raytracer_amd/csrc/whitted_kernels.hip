@@ -64,7 +64,7 @@ __device__ __forceinline__ double* wave_gstack(AT& a, size_t w) {
 // Without the deep stack the grid holds one wave per 8x8 tile of the strip; with it the grid
 // is fixed and its waves take pixels from the tile queue (TileQueue).
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? (DEEP ? 4 : RT_IMAGE_WAVES) : 3, (MW == 0 && !COUNT && !DEEP && RT_IMAGE_WAVES > 4) ? RT_IMAGE_WAVES : 4))) void whitted_kernel(KArgs a_) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? RT_IMAGE_WAVES : 3, (MW == 0 && !COUNT && RT_IMAGE_WAVES > 4) ? RT_IMAGE_WAVES : 4))) void whitted_kernel(KArgs a_) {
     extern __shared__ double lds_stack[];
     const KArgs& a = a_;
     const int lane = threadIdx.x & 63;
@@ -108,7 +108,7 @@ static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t strea
 // render, the grid is sized for the largest one and blocks outside a smaller one return at
 // once; with it the renders' tiles form one queue (tile_end = running totals).
 template <bool TREE, bool DEEP, bool LATE>
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(DEEP ? 4 : RT_IMAGE_WAVES, DEEP ? 4 : RT_IMAGE_WAVES)))
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(RT_IMAGE_WAVES, RT_IMAGE_WAVES)))
 void whitted_batch_kernel(KBatch, int n) {
     extern __shared__ double lds_stack[];
     const RT_CONST KBatch& b = *(const RT_CONST KBatch*)__builtin_amdgcn_kernarg_segment_ptr();  // the first argument
