@@ -107,8 +107,9 @@ def report(pmc_dir, trace_dir, events_json=None):
     times = per_config([d for _, d in sorted(durs)])
     events = json.load(open(events_json))["events"] if events_json else {}
     waves = ((W + 7) // 8) * ((H + 7) // 8)
-    print(f"Measured on the shipped image-only kernel, {W}x{H}, {waves} waves per launch; per launch, mean of {N - 1} launches.")
-    print(f"{'configuration':14s}{'kernel us':>11s}{'VALU insts':>14s}{'SALU insts':>14s}{'VALU/wave':>11s}{'rays':>12s}{'hits':>11s}{'feelers':>11s}")
+    print(f"Measured on the shipped image-only kernel, {W}x{H}, {waves} tiles of 64 pixels per launch (one wave each, or taken "
+          f"from the queue by a fixed grid); per launch, mean of {N - 1} launches.")
+    print(f"{'configuration':14s}{'kernel us':>11s}{'VALU insts':>14s}{'SALU insts':>14s}{'VALU/tile':>11s}{'rays':>12s}{'hits':>11s}{'feelers':>11s}")
     for name in LADDER:
         c, e = counters[name], events.get(name, {})
         print(f"{name:14s}{times[name]:11.1f}{c.get('SQ_INSTS_VALU', 0):14.0f}{c.get('SQ_INSTS_SALU', 0):14.0f}"
