@@ -19,7 +19,7 @@ from tests.parity import assert_parity  # noqa: E402
 
 def random_scene(rng):
     objs = []
-    for _ in range(int(rng.integers(1, 30))):
+    for _ in range(int(rng.integers(1, int(os.environ.get("RT_SOAK_MAX_OBJECTS", "29")) + 1))):
         kind = rng.random()
         refl = 0.0 if rng.random() < 0.3 else float(rng.uniform(0, 1))
         tr = 0.0 if rng.random() < 0.3 else float(rng.uniform(0, 1))
