@@ -90,6 +90,14 @@ typedef struct rt_light {
                                  so the image is the same.  Without the flag these outputs
                                  describe the reference's full ray tree.                  */
 
+#define RT_FLAG_NOGRID 16u    /* do not use the anchor grids: per light, and for the camera,
+                                 the lines through that point are sorted into cells that
+                                 list the spheres they may touch, so that a shadow feeler
+                                 (src/objects.h:35-46) and a primary ray (src/main.cc:37-47)
+                                 test the few spheres of one cell.  Used from 8 spheres on;
+                                 the results are identical bit for bit with and without.  */
+#define RT_FLAG_GRID 32u      /* use the anchor grids whatever the scene size            */
+
 /*
  * Per-render parameters: the values the reference hard-wires in Tracer()/main()
  * (frame size src/main.cc:215, FOV 60 src/main.cc:126, MAX_DEPTH src/main.cc:17,

@@ -23,6 +23,8 @@ RT_FLAG_COUNTERS = 1
 RT_FLAG_LINEAR = 2
 RT_FLAG_TREE = 4
 RT_FLAG_PRUNE = 8
+RT_FLAG_NOGRID = 16
+RT_FLAG_GRID = 32
 
 PRIM_DTYPE = np.dtype(
     [

@@ -3,12 +3,16 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
 #include <string>
 #include <vector>
 
+#include <array>
+
+#include "anchor_grid.h"
 #include "sphere_tree.h"
 #include "whitted_device.h"
 
@@ -42,6 +46,11 @@ struct rt_ctx {
     rt::FGeom* f_planes = nullptr;
     int32_t* d_planes_before = nullptr;
     int32_t n_nodes = 0, n_planes = 0;
+    // anchor grids (anchor_grid.h): one per light and one for the camera
+    rt::GridCell* d_grid_cells = nullptr;
+    rt::GridEntry* d_grid_entries = nullptr;
+    int32_t grid_res = 0;
+    float grid_eray_max = 0.0f;
     float* d_ltab = nullptr;   // light-anchored line-test constants, n_lights x ltab_stride x 4
     int32_t ltab_stride = 0;
     // grow-only device staging for rt_render's host outputs
@@ -167,6 +176,15 @@ bool use_tree(const rt_ctx* ctx, const rt_params* p) {
     return ctx->n_prims - ctx->n_planes >= kTreeMinSpheres;
 }
 
+// The anchor grids pay from a handful of spheres on (each feeler then tests the spheres of one
+// cell instead of all of them).
+constexpr int kGridMinSpheres = 8;
+bool use_grid(const rt_ctx* ctx, const rt_params* p) {
+    if (!ctx->d_grid_cells || (p->flags & RT_FLAG_NOGRID)) return false;
+    if (p->flags & RT_FLAG_GRID) return true;
+    return ctx->n_prims - ctx->n_planes >= kGridMinSpheres;
+}
+
 int make_args(rt_ctx* ctx, const rt_params* p, rt::KArgs& a) {
     if (check_params(p) != RT_OK) return fail(ctx, RT_ERR_ARG, "rt_params: value out of range");
     if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
@@ -180,6 +198,11 @@ int make_args(rt_ctx* ctx, const rt_params* p, rt::KArgs& a) {
     a.planes_before = ctx->d_planes_before;
     a.n_nodes = ctx->n_nodes;
     a.n_planes = ctx->n_planes;
+    a.grid_cells = ctx->d_grid_cells;
+    a.grid_entries = ctx->d_grid_entries;
+    a.grid_res = ctx->grid_res;
+    a.grid_half = 0.5f * static_cast<float>(ctx->grid_res);
+    a.grid_eray_max = ctx->grid_eray_max;
     a.ltab = ctx->d_ltab;
     a.ltab_stride = ctx->ltab_stride;
     a.scene_p1max = ctx->scene_p1max;
@@ -301,6 +324,8 @@ void rt_destroy(rt_ctx* ctx) {
         if (ctx->f_planes) (void)hipFree(ctx->f_planes);
         if (ctx->d_planes_before) (void)hipFree(ctx->d_planes_before);
         if (ctx->d_ltab) (void)hipFree(ctx->d_ltab);
+        if (ctx->d_grid_cells) (void)hipFree(ctx->d_grid_cells);
+        if (ctx->d_grid_entries) (void)hipFree(ctx->d_grid_entries);
         free_workspaces(ctx);
         for (hipEvent_t ev : ctx->part_done) (void)hipEventDestroy(ev);
         if (ctx->copies_done) (void)hipEventDestroy(ctx->copies_done);
@@ -452,26 +477,52 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
             float* rec = &ltab[(static_cast<size_t>(li) * lstride + i) * 4];
             rec[3] = -INFINITY;  // planes and padding: never ruled out here
             if (i >= static_cast<size_t>(n_prims) || prims[i].type != RT_PRIM_SPHERE) continue;
-            double L[3], n2 = 0.0, n1 = 0.0;
-            for (int c = 0; c < 3; ++c) {
-                L[c] = prims[i].p[c] - lights[li].pos[c];
-                n2 += L[c] * L[c];
-                n1 += std::fabs(L[c]);
-                rec[c] = static_cast<float>(L[c]);
-            }
-            const double thr = n2 - prims[i].q[0] * prims[i].q[0] - 20.0 * 6.0e-8 * n1 * n1;
-            float tf = static_cast<float>(thr);
-            tf = std::nextafter(std::nextafter(tf, -INFINITY), -INFINITY);
-            rec[3] = tf;
+            const double L[3] = {prims[i].p[0] - lights[li].pos[0], prims[i].p[1] - lights[li].pos[1],
+                                 prims[i].p[2] - lights[li].pos[2]};
+            rt::line_test_record(L, prims[i].q[0] * prims[i].q[0], rec);
         }
     }
     double tree_extent1 = 0.0;
     std::vector<rt::FGeom> tree = rt::build_sphere_tree(tsph, &tree_extent1);
     // the filter's per-ray error bound must cover the boxes too
     if (static_cast<float>(tree_extent1) * 1.0001f > p1max) p1max = static_cast<float>(tree_extent1) * 1.0001f;
+    // anchor grids: the lights, then the camera (the origin, src/view_frustum.h:40).  Built for
+    // rays whose origin lies within 255 scene extents of the scene.
+    rt::AnchorGrids grids;
+    if (!tsph.empty()) {
+        std::vector<rt::GridSphere> gs;
+        gs.reserve(tsph.size());
+        for (const rt::TreeSphere& t : tsph)
+            gs.push_back(rt::GridSphere{{t.c[0], t.c[1], t.c[2]}, prims[t.index].q[0] * prims[t.index].q[0], t.index});
+        std::vector<std::array<double, 3>> anchors;
+        for (int li = 0; li < n_lights; ++li) anchors.push_back({lights[li].pos[0], lights[li].pos[1], lights[li].pos[2]});
+        anchors.push_back({0.0, 0.0, 0.0});
+        int res = rt::anchor_grid_resolution(gs.size(), anchors.size());
+        if (const char* env = std::getenv("RT_GRID_RES")) {  // measurement aid
+            const int v = std::atoi(env);
+            if (v >= 1 && v <= 1024) res = v;
+        }
+        rt::build_anchor_grids(gs, anchors, 256.0 * static_cast<double>(p1max), res, size_t(8) << 20, &grids);
+    }
     DeviceGuard guard(ctx->device);
     RT_HIP_TRY(ctx, guard.status);
     ctx->have_scene = false;
+    if (ctx->d_grid_cells) RT_HIP_TRY(ctx, hipFree(ctx->d_grid_cells));
+    ctx->d_grid_cells = nullptr;
+    if (ctx->d_grid_entries) RT_HIP_TRY(ctx, hipFree(ctx->d_grid_entries));
+    ctx->d_grid_entries = nullptr;
+    ctx->grid_res = 0;
+    if (grids.res > 0) {
+        const size_t cb = grids.cells.size() * sizeof(rt::GridCell);
+        const size_t eb = (grids.entries.size() + 1) * sizeof(rt::GridEntry);  // never empty
+        RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_grid_cells), cb));
+        RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_grid_entries), eb));
+        RT_HIP_TRY(ctx, hipMemcpy(ctx->d_grid_cells, grids.cells.data(), cb, hipMemcpyHostToDevice));
+        if (!grids.entries.empty())
+            RT_HIP_TRY(ctx, hipMemcpy(ctx->d_grid_entries, grids.entries.data(), eb - sizeof(rt::GridEntry), hipMemcpyHostToDevice));
+        ctx->grid_res = grids.res;
+        ctx->grid_eray_max = grids.eray_max;
+    }
     if (ctx->f_geom) RT_HIP_TRY(ctx, hipFree(ctx->f_geom));
     ctx->f_geom = nullptr;
     if (ctx->f_tree) RT_HIP_TRY(ctx, hipFree(ctx->f_tree));
@@ -539,7 +590,7 @@ static int enqueue_render(rt_ctx* ctx, const rt_params* p, hipStream_t stream, v
                                    &deep_blocks)) != RT_OK)
             return rc;
     }
-    RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, tree, deep_blocks, stream));
+    RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, tree, use_grid(ctx, p), deep_blocks, stream));
     return RT_OK;
 }
 
@@ -585,6 +636,8 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
             return fail(first, RT_ERR_ARG, "rt_render_device_batch: scenes with and without a sphere tree in one batch");
     }
     const bool tree = use_tree(first, &params[0]);
+    bool grid = true;  // only when every render of the batch has its grids
+    for (int i = 0; i < n; ++i) grid = grid && use_grid(ctxs[i], &params[i]);
     DeviceGuard guard(first->device);
     RT_HIP_TRY(first, guard.status);
     for (int base = 0; base < n; base += rt::kMaxBatch) {
@@ -619,7 +672,7 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
                 rcg = attach_workspace(first, b.a, live, tiles, depth, ws, static_cast<hipStream_t>(stream), &deep_blocks);
             if (rcg != RT_OK) return rcg;
         }
-        RT_HIP_TRY(first, rt::launch_whitted_batch(b, live, tree, deep_blocks, static_cast<hipStream_t>(stream)));
+        RT_HIP_TRY(first, rt::launch_whitted_batch(b, live, tree, grid, deep_blocks, static_cast<hipStream_t>(stream)));
     }
     return RT_OK;
 }
@@ -861,7 +914,7 @@ static rt_params mode_params(uint32_t flags) {
     std::memset(&p, 0, sizeof p);
     p.width = p.height = 8; p.max_depth = 2; p.band_rows = 8; p.band_step = 1; p.band_count = 1;
     p.fov_deg = 60.0;
-    p.flags = flags & (RT_FLAG_LINEAR | RT_FLAG_TREE);
+    p.flags = flags & (RT_FLAG_LINEAR | RT_FLAG_TREE | RT_FLAG_NOGRID | RT_FLAG_GRID);
     return p;
 }
 
@@ -881,7 +934,7 @@ int rt_debug_nearest(rt_ctx* ctx, const double* rays, int32_t n, uint32_t flags,
     if ((rc = reserve(ctx, ctx->dbg_t, N * 8)) != RT_OK) return rc;
     if ((rc = reserve(ctx, ctx->dbg_unit, N * 4)) != RT_OK) return rc;
     RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->dbg_in.ptr, rays, N * 48, hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP_TRY(ctx, rt::launch_debug_nearest(a, use_tree(ctx, &p), static_cast<const double*>(ctx->dbg_in.ptr), n,
+    RT_HIP_TRY(ctx, rt::launch_debug_nearest(a, use_tree(ctx, &p), use_grid(ctx, &p), static_cast<const double*>(ctx->dbg_in.ptr), n,
                                              static_cast<int32_t*>(ctx->dbg_unit.ptr),
                                              static_cast<double*>(ctx->dbg_t.ptr), ctx->stream));
     RT_HIP_TRY(ctx, hipMemcpyAsync(index_out, ctx->dbg_unit.ptr, N * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -909,7 +962,7 @@ int rt_debug_occluder(rt_ctx* ctx, const double* points, int32_t n, int32_t ligh
     if ((rc = reserve(ctx, ctx->dbg_t, N * 8)) != RT_OK) return rc;
     if ((rc = reserve(ctx, ctx->dbg_unit, N * 4)) != RT_OK) return rc;
     RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->dbg_in.ptr, points, N * 24, hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP_TRY(ctx, rt::launch_debug_occluder(a, use_tree(ctx, &p), light, self,
+    RT_HIP_TRY(ctx, rt::launch_debug_occluder(a, use_tree(ctx, &p), use_grid(ctx, &p), light, self,
                                               static_cast<const double*>(ctx->dbg_in.ptr), n,
                                               static_cast<int32_t*>(ctx->dbg_unit.ptr),
                                               static_cast<double*>(ctx->dbg_t.ptr), ctx->stream));

@@ -60,6 +60,22 @@ struct FGeom {
 };
 static_assert(sizeof(FGeom) == 32, "record size");
 
+// Anchor grids (anchor_grid.h): for every light, and for the camera, the lines through that
+// point are sorted into the cells of three cube faces; a cell lists the spheres some line of
+// the cell may touch, in container order.  A shadow feeler (its line passes through its
+// light) and a primary ray (through the camera) then test the few spheres of one cell
+// instead of walking the scene.
+struct GridCell {
+    uint32_t start, count;   // entries [start, start + count) of the entry table
+};
+struct GridEntry {
+    float l[3];              // sphere centre - anchor
+    float thr;               // threshold of the light-anchored line test (line_miss_from_light)
+    int32_t index;           // the sphere's position in the caller's object list
+    int32_t pad[3];
+};
+static_assert(sizeof(GridCell) == 8 && sizeof(GridEntry) == 32, "record size");
+
 // Per-lane stack entry: origin xyz, direction xyz, and one field that holds the path weight
 // (float) and the node number.
 constexpr int kStackFields = 7;
@@ -78,6 +94,8 @@ struct KArgs {
                                // (stack_workspace_bytes), null if unused
     unsigned int* tile_queue;  // deep-stack launches: the next tile to hand out (zeroed before
                                // every launch), null otherwise
+    const GridCell* grid_cells;    // anchor grids: [anchor][face][v][u], anchors = the lights, then the
+    const GridEntry* grid_entries; // camera; null = not built
     const float* ltab;         // per light, ltab_stride records {c - P (xyz), threshold}: see
                                // line_miss_from_light(); planes carry threshold -inf
     uint8_t* bgr;
@@ -99,6 +117,9 @@ struct KArgs {
     float scene_p1max;         // >= |centre|_1 of every sphere (filter bound)
     uint32_t band_magic;       // ceil(2^32 / band_rows): k / band_rows = mulhi(k, band_magic), k < 2^16
     int32_t primary_in_range;  // every primary ray's p1 passes the range guard of unit()
+    int32_t grid_res;          // cells per face edge
+    float grid_half;           // grid_res / 2
+    float grid_eray_max;       // the grids hold for rays whose FilterRay::eray is at most this
     int32_t prune;             // ids, masks and counters describe the walk without the children of
                                // weight zero (the image-only kernels always leave those out)
 };
@@ -171,7 +192,7 @@ struct KBatch {
 };
 static_assert(sizeof(KBatch) <= 3072, "kernel argument segment");
 // deep_blocks: grid of a deep-stack launch (deep_grid_blocks), ignored otherwise.
-hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, int deep_blocks, hipStream_t stream);
+hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, bool grid, int deep_blocks, hipStream_t stream);
 
 // The library's built-in workspace (a file-scope device array of kWorkspaceMaxBytes): its
 // address on the CURRENT device, looked up once per device.
@@ -179,16 +200,17 @@ hipError_t static_workspace(int device, void** ptr);
 
 // Enqueue the render of one strip on `stream`.  emit = write hit_id/masks (pointers in
 // `a` that are null are skipped), count = add event counts to a.counters.
+// grid = use the anchor grids (a.grid_cells must be set).
 // deep_blocks: grid of a deep-stack launch (deep_grid_blocks), ignored otherwise.
-hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, int deep_blocks, hipStream_t stream);
+hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, bool grid, int deep_blocks, hipStream_t stream);
 
 
 // Enqueue the nearest-hit hook (rt_debug_nearest); only the scene fields of `a` are read.
-hipError_t launch_debug_nearest(const KArgs& a, bool tree, const double* rays, int n, int32_t* index_out, double* t_out,
+hipError_t launch_debug_nearest(const KArgs& a, bool tree, bool grid, const double* rays, int n, int32_t* index_out, double* t_out,
                                 hipStream_t stream);
 
 // Enqueue the feeler-search hook (rt_debug_occluder); only the scene fields of `a` are read.
-hipError_t launch_debug_occluder(const KArgs& a, bool tree, int light, int self, const double* points, int n,
+hipError_t launch_debug_occluder(const KArgs& a, bool tree, bool grid, int light, int self, const double* points, int n,
                                  int32_t* first_out, double* factor_out, hipStream_t stream);
 
 // Enqueue the collision-test hook (rt_debug_intersect).

@@ -559,18 +559,20 @@ __device__ __forceinline__ void near_candidate(const FNode& nd, cdata_t geom, in
                                                double& nearest, int& cur) {
     if (!certain_miss_sphere(nd.c0, nd.c1, nd.c2, nd.h0, fr)) near_exact_candidate<true>(geom, idx, o, d, nearest, cur);
 }
+// The planes of a scene whose spheres are searched through the tree or a grid: a short list
+// in front of that search.
 template <bool COUNT, typename AT>
-__device__ __forceinline__ void find_nearest_tree(AT& a, cdata_t geom, V3 o, V3 d, double& nearest, int& cur,
-                                                  uint32_t& c_sph, uint32_t& c_pln) {
-    const FilterRay fr = filter_ray(o, d, a.scene_p1max);
-#ifndef RT_PHASE_PROFILE
-    if (COUNT) { c_sph += (uint32_t)(a.n_prims - a.n_planes); c_pln += (uint32_t)a.n_planes; }
-#endif
+__device__ __forceinline__ void near_planes(AT& a, cdata_t geom, const FilterRay& fr, V3 o, V3 d, double& nearest, int& cur) {
     cfdata_t pp = (cfdata_t)(const float*)a.planes;
     for (int k = 0; k < a.n_planes; ++k, pp += 8) {
         const FRec gf = load_rec(pp);
         near_candidate<COUNT>(gf, geom, __float_as_int(pp[6]), fr, o, d, nearest, cur);
     }
+}
+template <bool COUNT, typename AT>
+__device__ __forceinline__ void find_nearest_tree(AT& a, cdata_t geom, const FilterRay& fr, V3 o, V3 d, double& nearest,
+                                                  int& cur, uint32_t& c_sph) {
+    near_planes<COUNT>(a, geom, fr, o, d, nearest, cur);
     // The position in the tree is kept as a byte offset (one scalar add per step).
     const RT_CONST char* tree = (const RT_CONST char*)(const char*)a.tree;
     const uint32_t end = (uint32_t)a.n_nodes << 5;
@@ -613,14 +615,19 @@ __device__ __forceinline__ void feeler_candidate(const FNode& nd, cdata_t geom, 
     feeler_exact_candidate<true>(certain_miss_sphere(nd.c0, nd.c1, nd.c2, nd.h0, fr), geom, idx, ip, fdir, cur, best, pa, pb);
 }
 template <typename AT>
-__device__ __forceinline__ int find_occluder_tree(AT& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur,
-                                                  double& pa, double& pb, uint32_t& c_nodes) {
-    int best = 0x7fffffff;
+__device__ __forceinline__ void feeler_planes(AT& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur, int& best,
+                                              double& pa, double& pb) {
     cfdata_t pp = (cfdata_t)(const float*)a.planes;
     for (int k = 0; k < a.n_planes; ++k, pp += 8) {
         const FRec gf = load_rec(pp);
         feeler_candidate(gf, geom, __float_as_int(pp[6]), fr, ip, fdir, cur, best, pa, pb);
     }
+}
+template <typename AT>
+__device__ __forceinline__ int find_occluder_tree(AT& a, cdata_t geom, const FilterRay& fr, V3 ip, V3 fdir, int cur,
+                                                  double& pa, double& pb, uint32_t& c_nodes) {
+    int best = 0x7fffffff;
+    feeler_planes(a, geom, fr, ip, fdir, cur, best, pa, pb);
     const RT_CONST char* tree = (const RT_CONST char*)(const char*)a.tree;
     const uint32_t end = (uint32_t)a.n_nodes << 5;
     uint32_t off = 0;
@@ -638,6 +645,79 @@ __device__ __forceinline__ int find_occluder_tree(AT& a, cdata_t geom, const Fil
         off = ((open & ~box_miss(nd, fr)) != 0ull) ? off : (uint32_t)nd.skip << 5;
     }
     return best;
+}
+
+// ---- anchor grids (anchor_grid.h) -------------------------------------------------------
+// The list of the cell that the line with (float) direction d through anchor `anchor` falls
+// into; `ok` is false for a direction that is not of unit length (the caller then takes the
+// general path).  The cell is found with float arithmetic whose error (below 1e-6 in the
+// cell coordinates) the builder has allowed for.
+struct GridList {
+    const GridEntry* e;
+    uint32_t n;
+};
+template <typename AT>
+__device__ __forceinline__ GridList grid_list(AT& a, int anchor, F3 d, bool& ok) {
+    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+    const bool fx = (ax >= ay) & (ax >= az);
+    const bool fy = !fx & (ay >= az);
+    // face 0: k = x, (i, j) = (y, z); face 1: k = y, (x, z); face 2: k = z, (x, y)
+    const float dk = fx ? d.x : (fy ? d.y : d.z);
+    const float di = fx ? d.y : d.x;
+    const float dj = (fx | fy) ? d.z : d.y;
+    ok = __builtin_fabsf(dk) > 0.5f;  // a unit vector's largest component is at least 0.577
+    const float inv = __builtin_amdgcn_rcpf(dk);
+    const float half = a.grid_half;
+    const float top = half + half - 1.0f;
+    const float fu = __builtin_amdgcn_fmed3f(__builtin_fmaf(di * inv, half, half), 0.0f, top);
+    const float fv = __builtin_amdgcn_fmed3f(__builtin_fmaf(dj * inv, half, half), 0.0f, top);
+    const int face = fx ? 0 : (fy ? 1 : 2);
+    const int R = a.grid_res;
+    const uint32_t ci = (uint32_t)(((anchor * 3 + face) * R + (int)fv) * R + (int)fu);
+    const GridCell c = a.grid_cells[ok ? ci : 0u];
+    GridList gl;
+    gl.e = a.grid_entries + c.start;
+    gl.n = ok ? c.count : 0u;
+    return gl;
+}
+__device__ __forceinline__ LRec entry_lrec(const GridEntry* e) {
+    LRec l;
+    l.x = e->l[0]; l.y = e->l[1]; l.z = e->l[2]; l.thr = e->thr;
+    return l;
+}
+// Shadow feeler over the spheres of its cell (src/objects.h:31-47).  The list ascends in the
+// container index, so the first sphere of it that the feeler hits is the first occluder among
+// the spheres; `best` comes in as the index of the first occluding plane (or INT_MAX) and
+// ends the search as soon as the list passes it.  Every lane walks its own list.
+template <typename AT>
+__device__ __forceinline__ void find_occluder_grid(AT& a, GridList gl, const FilterRay& fr, V3 ip, V3 fdir, int cur,
+                                                   int& best, double& pa, double& pb) {
+    const GridEntry* e = gl.e;
+    for (uint32_t n = gl.n; n != 0u; --n, ++e) {
+        const int idx = e->index;
+        if (idx >= best) break;
+        if ((idx == cur) | line_miss_from_light(entry_lrec(e), fr)) continue;
+        double na = pa, nb = pb;
+        const bool hit = collides<true>(a.geom[idx], ip, fdir, na, nb);
+        pa = na; pb = nb;
+        if (hit) { best = idx; break; }
+    }
+}
+// Nearest hit of a primary ray over the spheres of its cell of the camera's grid
+// (src/main.cc:37-47; the planes have been tested by the caller).
+template <typename AT>
+__device__ __forceinline__ void find_nearest_grid(AT& a, GridList gl, const FilterRay& fr, V3 o, V3 d, double& nearest,
+                                                  int& cur) {
+    const GridEntry* e = gl.e;
+    for (uint32_t n = gl.n; n != 0u; --n, ++e) {
+        if (line_miss_from_light(entry_lrec(e), fr)) continue;
+        const int idx = e->index;
+        double t;
+        const bool hit = test_collision<true>(a.geom[idx], o, d, t);
+        const bool closer = hit && (t < nearest || (t == nearest && idx < cur));
+        nearest = closer ? t : nearest;
+        cur = closer ? idx : cur;
+    }
 }
 
 // The object loops take the scene four records at a time: the float records of a group
@@ -724,13 +804,30 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 
 // The nearest hit of a ray over all objects (src/main.cc:37-47): `cur` = its index (-1 =
 // none), `nearest` = its t.
-template <bool COUNT, bool TREE, typename AT>
-__device__ __forceinline__ void find_nearest(AT& a, cdata_t geom, cfdata_t fgeom, V3 o, V3 d, double& nearest,
-                                             int& cur, uint32_t& c_sph, uint32_t& c_pln) {
-    if (TREE) {
-        find_nearest_tree<COUNT>(a, geom, o, d, nearest, cur, c_sph, c_pln);
+// GRID: a wave whose rays all start at the camera (`primary`; the origin is then exactly
+// zero) searches the spheres through the camera's anchor grid.
+template <bool COUNT, bool TREE, bool GRID, typename AT>
+__device__ __forceinline__ void find_nearest(AT& a, cdata_t geom, cfdata_t fgeom, V3 o, V3 d, bool primary,
+                                             double& nearest, int& cur, uint32_t& c_sph, uint32_t& c_pln) {
+    const FilterRay fr = filter_ray(o, d, a.scene_p1max);
+    bool by_grid = false;
+    GridList gl;
+    if (GRID) {
+        if (all_lanes(primary)) {
+            bool ok;
+            gl = grid_list(a, a.n_lights, fr.d, ok);
+            by_grid = all_lanes(ok & (fr.eray <= a.grid_eray_max));
+        }
+    }
+#ifndef RT_PHASE_PROFILE
+    if (COUNT && (TREE || by_grid)) { c_sph += (uint32_t)(a.n_prims - a.n_planes); c_pln += (uint32_t)a.n_planes; }
+#endif
+    if (GRID && by_grid) {
+        near_planes<COUNT>(a, geom, fr, o, d, nearest, cur);
+        find_nearest_grid(a, gl, fr, o, d, nearest, cur);
+    } else if (TREE) {
+        find_nearest_tree<COUNT>(a, geom, fr, o, d, nearest, cur, c_sph);
     } else {
-        const FilterRay fr = filter_ray(o, d, a.scene_p1max);
         cfdata_t fp = fgeom;
         cdata_t gp = geom;
         int base = 0;
@@ -753,12 +850,22 @@ __device__ __forceinline__ void find_nearest(AT& a, cdata_t geom, cfdata_t fgeom
 // One shadow feeler (src/objects.h:31-47): the index of the first occluder in container
 // order between `ip` and light `li` (never `cur`, the shaded object), or -1; `occl`
 // receives its transmission factor.  `ffr` must hold filter_origin(ip).
+// The collision tests the reference makes for a feeler whose first occluder is `first`
+// (-1: none): objects 0..first, all of them when there is none, never `cur`.
+template <typename AT>
+__device__ __forceinline__ void count_feeler_tests(AT& a, int first, int cur, bool cur_plane, uint32_t& c_sph, uint32_t& c_pln) {
+    const int last = (first >= 0) ? first + 1 : a.n_prims;
+    const int tested = last - ((cur < last) ? 1 : 0);
+    const int planes = a.planes_before[last] - ((cur_plane && cur < last) ? 1 : 0);
+    c_pln += (uint32_t)planes;
+    c_sph += (uint32_t)(tested - planes);
+}
+// The search without an anchor grid: the sphere tree, or the object list in container order.
 template <bool COUNT, bool TREE, bool LATE, typename AT>
-__device__ __forceinline__ int shadow_feeler(AT& a, cdata_t geom, cfdata_t fgeom, cfdata_t ltab, int li,
-                                             FilterRay& ffr, V3 ip, V3 fdir, int cur, bool cur_plane, float& occl,
-                                             uint32_t& c_sph, uint32_t& c_pln) {
+__device__ __forceinline__ int shadow_feeler_general(AT& a, cdata_t geom, cfdata_t fgeom, cfdata_t ltab, int li,
+                                                     FilterRay& ffr, V3 ip, V3 fdir, int cur, bool cur_plane, float& occl,
+                                                     uint32_t& c_sph, uint32_t& c_pln) {
     int first = -1;  // index of the first occluder in container order
-    set_dir(ffr, fdir);
     if (TREE) {
         // the walk meets occluders in any order: it only keeps the one with the
         // smallest index, whose factor is worked out afterwards
@@ -767,15 +874,7 @@ __device__ __forceinline__ int shadow_feeler(AT& a, cdata_t geom, cfdata_t fgeom
         first = (best != 0x7fffffff) ? best : -1;
         if (first >= 0) occl = occluder_factor(a.geom + first, ip, fdir, pa, pb);
 #ifndef RT_PHASE_PROFILE
-        if (COUNT) {
-            // the tests the reference makes: objects 0..first (all when open), never `cur`
-            const bool cur_pl = cur_plane;
-            const int last = (first >= 0) ? first + 1 : a.n_prims;
-            const int tested = last - ((cur < last) ? 1 : 0);
-            const int planes = a.planes_before[last] - ((cur_pl && cur < last) ? 1 : 0);
-            c_pln += (uint32_t)planes;
-            c_sph += (uint32_t)(tested - planes);
-        }
+        if (COUNT) count_feeler_tests(a, first, cur, cur_plane, c_sph, c_pln);
 #endif
     } else {
         cfdata_t lp = ltab + (size_t)li * a.ltab_stride * 4;
@@ -802,6 +901,34 @@ __device__ __forceinline__ int shadow_feeler(AT& a, cdata_t geom, cfdata_t fgeom
                 feeler_slot<COUNT, LATE>(lr[j], fp, gp, j, base + j, j < rem, ffr, ip, fdir, cur, first, occl,
                                    c_sph, c_pln);
         }
+    }
+    return first;
+}
+// GRID: the spheres are searched through the light's anchor grid (every lane its own cell);
+// lanes whose ray is outside the range the grids were built for take the general search.
+template <bool COUNT, bool TREE, bool LATE, bool GRID, typename AT>
+__device__ __forceinline__ int shadow_feeler(AT& a, cdata_t geom, cfdata_t fgeom, cfdata_t ltab, int li,
+                                             FilterRay& ffr, V3 ip, V3 fdir, int cur, bool cur_plane, float& occl,
+                                             uint32_t& c_sph, uint32_t& c_pln) {
+    set_dir(ffr, fdir);
+    if (!GRID) return shadow_feeler_general<COUNT, TREE, LATE>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur, cur_plane, occl, c_sph, c_pln);
+    int first = -1;
+    bool ok;
+    const GridList gl = grid_list(a, li, ffr.d, ok);
+    ok = ok & (ffr.eray <= a.grid_eray_max);
+    if (ok) {
+        double pa = 0.0, pb = 0.0;  // see collides()
+        int best = 0x7fffffff;
+        feeler_planes(a, geom, ffr, ip, fdir, cur, best, pa, pb);
+        find_occluder_grid(a, gl, ffr, ip, fdir, cur, best, pa, pb);
+        first = (best != 0x7fffffff) ? best : -1;
+        if (first >= 0) occl = occluder_factor(a.geom + first, ip, fdir, pa, pb);
+#ifndef RT_PHASE_PROFILE
+        if (COUNT) count_feeler_tests(a, first, cur, cur_plane, c_sph, c_pln);
+#endif
+    }
+    if (!all_lanes(ok)) {
+        if (!ok) first = shadow_feeler_general<COUNT, TREE, false>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur, cur_plane, occl, c_sph, c_pln);
     }
     return first;
 }
@@ -893,6 +1020,7 @@ __device__ __forceinline__ void take_pixels(TileQueue& f, CArgs*& ap, bool& have
 // DEEP = the stack may reach its global-memory part (max_depth > 3 + kStackLdsEntries);
 //        without it that code is left out, which the register allocation needs.
 // LATE = see feeler_slot() (container-order shadow loops of scenes with many lights).
+// GRID = shadow feelers and primary rays find their spheres through the anchor grids.
 // The step itself (whitted_walk_step.inc.h) is shared by the two functions below.
 
 #ifdef RT_PHASE_PROFILE
@@ -954,7 +1082,7 @@ __device__ __forceinline__ void store_pixel(AT& a, int x, int k, float cr, float
 
 // One wave, one 8x8 tile: (x, k) = this lane's column and strip row; `have` is false for
 // lanes without a pixel.
-template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, typename AT>
+template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, bool GRID, typename AT>
 __device__ __forceinline__ void trace_tile(AT& a, const int x, const int k, bool have, double* stk, double* gstk,
                                            const int lane, uint32_t (&cnt)[8]) {
     const cdata_t geom = (cdata_t)(const double*)a.geom;
@@ -996,7 +1124,7 @@ __device__ __forceinline__ void trace_tile(AT& a, const int x, const int k, bool
 }
 
 // One wave of a launch with a fixed grid: pixels from the tile queue until it is empty.
-template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
+template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, bool GRID>
 __device__ __forceinline__ void trace_queue(TileQueue& feed, double* stk, double* gstk, const int lane,
                                             uint32_t (&cnt)[8]) {
     CArgs* ap = feed.renders + feed.cur;

@@ -17,6 +17,11 @@ constexpr int kLateMinLights = 4;
 #ifndef RT_IMAGE_WAVES
 #define RT_IMAGE_WAVES 5
 #endif
+// The same for the image-only kernels that use the anchor grids.
+#ifndef RT_GRID_WAVES
+#define RT_GRID_WAVES 5
+#endif
+constexpr int image_waves(bool grid) { return grid ? RT_GRID_WAVES : RT_IMAGE_WAVES; }
 
 template <bool COUNT, typename AT>
 __device__ __forceinline__ void flush_counters(AT& a, const uint32_t (&cnt)[8], int lane) {
@@ -63,8 +68,8 @@ __device__ __forceinline__ double* wave_gstack(AT& a, size_t w) {
 
 // Without the deep stack the grid holds one wave per 8x8 tile of the strip; with it the grid
 // is fixed and its waves take pixels from the tile queue (TileQueue).
-template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? RT_IMAGE_WAVES : 3, (MW == 0 && !COUNT && RT_IMAGE_WAVES > 4) ? RT_IMAGE_WAVES : 4))) void whitted_kernel(KArgs a_) {
+template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, bool GRID>
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? image_waves(GRID) : 3, (MW == 0 && !COUNT && image_waves(GRID) > 4) ? image_waves(GRID) : 4))) void whitted_kernel(KArgs a_) {
     extern __shared__ double lds_stack[];
     const KArgs& a = a_;
     const int lane = threadIdx.x & 63;
@@ -78,27 +83,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         feed.tile_end = nullptr;
         feed.queue = a.tile_queue;
         feed.n_tiles = a.tiles_x * a.tiles_y;
-        trace_queue<MW, COUNT, TREE, DEEP, LATE>(feed, stk, gstk, lane, cnt);
+        trace_queue<MW, COUNT, TREE, DEEP, LATE, GRID>(feed, stk, gstk, lane, cnt);
     } else {
         const int tx = blockIdx.x * kWavesPerBlock + wave;  // a block = 4 tiles side by side
         const int ty = blockIdx.y;
         const int x = tx * kTile + (lane & 7);
         const int k = ty * kTile + (lane >> 3);  // row in strip order
-        trace_tile<MW, COUNT, TREE, DEEP, LATE>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
+        trace_tile<MW, COUNT, TREE, DEEP, LATE, GRID>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
     }
     flush_counters<COUNT>(a, cnt, lane);
 }
 
-template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE>
+template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, bool GRID>
 static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t stream) {
     const int bx = (a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     if (bx <= 0 || a.tiles_y <= 0) return hipSuccess;
     const size_t lds = DEEP ? stack_lds_bytes(a.max_depth) : tile_stack_lds_bytes(a.max_depth);
     if (DEEP || TREE) {
         if (deep_blocks < 1 || deep_blocks > (DEEP ? kDeepMaxBlocks : kQueueMaxBlocks) || !a.tile_queue || (DEEP && !a.gstack)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE>), dim3(deep_blocks), dim3(64 * kWavesPerBlock), lds, stream, a);
+        hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE, GRID>), dim3(deep_blocks), dim3(64 * kWavesPerBlock), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
+        hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE, GRID>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
     }
     return hipGetLastError();
 }
@@ -107,8 +112,8 @@ static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t strea
 // argument segment.  Image-only variant.  Without the deep stack blockIdx.z selects the
 // render, the grid is sized for the largest one and blocks outside a smaller one return at
 // once; with it the renders' tiles form one queue (tile_end = running totals).
-template <bool TREE, bool DEEP, bool LATE>
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(RT_IMAGE_WAVES, RT_IMAGE_WAVES)))
+template <bool TREE, bool DEEP, bool LATE, bool GRID>
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(image_waves(GRID), image_waves(GRID) > 4 ? image_waves(GRID) : 4)))
 void whitted_batch_kernel(KBatch, int n) {
     extern __shared__ double lds_stack[];
     const RT_CONST KBatch& b = *(const RT_CONST KBatch*)__builtin_amdgcn_kernarg_segment_ptr();  // the first argument
@@ -126,7 +131,7 @@ void whitted_batch_kernel(KBatch, int n) {
         feed.tile_end = b.tile_end;
         feed.queue = b.a[0].tile_queue;
         feed.n_tiles = b.tile_end[n - 1];
-        trace_queue<0, false, TREE, DEEP, LATE>(feed, stk, gstk, lane, cnt);
+        trace_queue<0, false, TREE, DEEP, LATE, GRID>(feed, stk, gstk, lane, cnt);
     } else {
         CArgs& a = b.a[blockIdx.z];
         if ((int)blockIdx.y >= a.tiles_y || (int)(blockIdx.x * kWavesPerBlock) >= a.tiles_x) return;
@@ -135,11 +140,18 @@ void whitted_batch_kernel(KBatch, int n) {
         const int ty = blockIdx.y;
         const int x = tx * kTile + (lane & 7);
         const int k = ty * kTile + (lane >> 3);
-        trace_tile<0, false, TREE, DEEP, LATE>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
+        trace_tile<0, false, TREE, DEEP, LATE, GRID>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
     }
 }
 
-hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, int deep_blocks, hipStream_t stream) {
+template <bool TREE, bool DEEP>
+static void launch_batch_td(const KBatch& b, int n, bool late, bool grid, dim3 g, dim3 blk, size_t lds, hipStream_t stream) {
+    if (grid) hipLaunchKernelGGL((whitted_batch_kernel<TREE, DEEP, false, true>), g, blk, lds, stream, b, n);
+    else if (late && !TREE) hipLaunchKernelGGL((whitted_batch_kernel<TREE, DEEP, !TREE, false>), g, blk, lds, stream, b, n);
+    else hipLaunchKernelGGL((whitted_batch_kernel<TREE, DEEP, false, false>), g, blk, lds, stream, b, n);
+}
+
+hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, bool grid, int deep_blocks, hipStream_t stream) {
     int bx = 0, by = 0, depth = 0;
     for (int i = 0; i < n; ++i) {
         const KArgs& a = b.a[i];
@@ -153,53 +165,59 @@ hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, int deep_bloc
     const size_t lds = deep ? stack_lds_bytes(depth) : tile_stack_lds_bytes(depth);
     if (queue && (deep_blocks < 1 || deep_blocks > (deep ? kDeepMaxBlocks : kQueueMaxBlocks) || !b.a[0].tile_queue || (deep && !b.a[0].gstack)))
         return hipErrorInvalidValue;
-    const dim3 grid = queue ? dim3(deep_blocks) : dim3(bx, by, n);
+    const dim3 g = queue ? dim3(deep_blocks) : dim3(bx, by, n);
     const dim3 block(64 * kWavesPerBlock);
     bool late = !tree;  // every render of the batch must have many lights
-    for (int i = 0; i < n; ++i) late = late && b.a[i].n_lights >= kLateMinLights;
-    if (tree && deep) hipLaunchKernelGGL((whitted_batch_kernel<true, true, false>), grid, block, lds, stream, b, n);
-    else if (tree) hipLaunchKernelGGL((whitted_batch_kernel<true, false, false>), grid, block, lds, stream, b, n);
-    else if (deep && late) hipLaunchKernelGGL((whitted_batch_kernel<false, true, true>), grid, block, lds, stream, b, n);
-    else if (deep) hipLaunchKernelGGL((whitted_batch_kernel<false, true, false>), grid, block, lds, stream, b, n);
-    else if (late) hipLaunchKernelGGL((whitted_batch_kernel<false, false, true>), grid, block, lds, stream, b, n);
-    else hipLaunchKernelGGL((whitted_batch_kernel<false, false, false>), grid, block, lds, stream, b, n);
+    for (int i = 0; i < n; ++i) {
+        late = late && b.a[i].n_lights >= kLateMinLights;
+        if (grid && !b.a[i].grid_cells) return hipErrorInvalidValue;
+    }
+    if (tree && deep) launch_batch_td<true, true>(b, n, late, grid, g, block, lds, stream);
+    else if (tree) launch_batch_td<true, false>(b, n, late, grid, g, block, lds, stream);
+    else if (deep) launch_batch_td<false, true>(b, n, late, grid, g, block, lds, stream);
+    else launch_batch_td<false, false>(b, n, late, grid, g, block, lds, stream);
     return hipGetLastError();
 }
 
-// The late-predicate shadow loop exists for the image-only kernel without the tree only.
+// The late-predicate shadow loop exists for the image-only kernel without the tree only; a
+// launch that uses the anchor grids has no use for it.
 template <int MW, bool COUNT, bool TREE, bool DEEP>
-static hipError_t launch_ttd(const KArgs& a, int deep_blocks, hipStream_t stream) {
+static hipError_t launch_ttd(const KArgs& a, bool grid, int deep_blocks, hipStream_t stream) {
+    if (grid) {
+        if (!a.grid_cells || !a.grid_entries) return hipErrorInvalidValue;
+        return launch_ttdl<MW, COUNT, TREE, DEEP, false, true>(a, deep_blocks, stream);
+    }
     if (MW == 0 && !COUNT && !TREE && a.n_lights >= kLateMinLights)
-        return launch_ttdl<MW, COUNT, TREE, DEEP, (MW == 0 && !COUNT && !TREE)>(a, deep_blocks, stream);
-    return launch_ttdl<MW, COUNT, TREE, DEEP, false>(a, deep_blocks, stream);
+        return launch_ttdl<MW, COUNT, TREE, DEEP, (MW == 0 && !COUNT && !TREE), false>(a, deep_blocks, stream);
+    return launch_ttdl<MW, COUNT, TREE, DEEP, false, false>(a, deep_blocks, stream);
 }
 
 template <int MW, bool COUNT, bool TREE>
-static hipError_t launch_tt(const KArgs& a, int deep_blocks, hipStream_t stream) {
-    if (stack_global_entries(a.max_depth) == 0) return launch_ttd<MW, COUNT, TREE, false>(a, deep_blocks, stream);
-    return launch_ttd<MW, COUNT, TREE, true>(a, deep_blocks, stream);
+static hipError_t launch_tt(const KArgs& a, bool grid, int deep_blocks, hipStream_t stream) {
+    if (stack_global_entries(a.max_depth) == 0) return launch_ttd<MW, COUNT, TREE, false>(a, grid, deep_blocks, stream);
+    return launch_ttd<MW, COUNT, TREE, true>(a, grid, deep_blocks, stream);
 }
 
 template <int MW, bool COUNT>
-static hipError_t launch_t(const KArgs& a, bool tree, int deep_blocks, hipStream_t stream) {
-    return tree ? launch_tt<MW, COUNT, true>(a, deep_blocks, stream) : launch_tt<MW, COUNT, false>(a, deep_blocks, stream);
+static hipError_t launch_t(const KArgs& a, bool tree, bool grid, int deep_blocks, hipStream_t stream) {
+    return tree ? launch_tt<MW, COUNT, true>(a, grid, deep_blocks, stream) : launch_tt<MW, COUNT, false>(a, grid, deep_blocks, stream);
 }
 
-hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, int deep_blocks, hipStream_t stream) {
+hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, bool grid, int deep_blocks, hipStream_t stream) {
     const int mw = emit ? a.mask_words : 0;
     if (count) {
         switch (mw) {
-            case 0: return launch_t<0, true>(a, tree, deep_blocks, stream);
-            case 1: return launch_t<1, true>(a, tree, deep_blocks, stream);
-            case 2: return launch_t<2, true>(a, tree, deep_blocks, stream);
-            case 4: return launch_t<4, true>(a, tree, deep_blocks, stream);
+            case 0: return launch_t<0, true>(a, tree, grid, deep_blocks, stream);
+            case 1: return launch_t<1, true>(a, tree, grid, deep_blocks, stream);
+            case 2: return launch_t<2, true>(a, tree, grid, deep_blocks, stream);
+            case 4: return launch_t<4, true>(a, tree, grid, deep_blocks, stream);
         }
     } else {
         switch (mw) {
-            case 0: return launch_t<0, false>(a, tree, deep_blocks, stream);
-            case 1: return launch_t<1, false>(a, tree, deep_blocks, stream);
-            case 2: return launch_t<2, false>(a, tree, deep_blocks, stream);
-            case 4: return launch_t<4, false>(a, tree, deep_blocks, stream);
+            case 0: return launch_t<0, false>(a, tree, grid, deep_blocks, stream);
+            case 1: return launch_t<1, false>(a, tree, grid, deep_blocks, stream);
+            case 2: return launch_t<2, false>(a, tree, grid, deep_blocks, stream);
+            case 4: return launch_t<4, false>(a, tree, grid, deep_blocks, stream);
         }
     }
     return hipErrorInvalidValue;
@@ -232,7 +250,7 @@ __global__ void debug_intersect_kernel(const DGeom* geom_, const FGeom* fgeom_, 
 }
 
 // rt_debug_occluder: one lane per point, the feeler search exactly as the render kernel runs it.
-template <bool TREE>
+template <bool TREE, bool GRID>
 __global__ void debug_occluder_kernel(KArgs a, int light, int self, const double* points, int n, int32_t* first_out,
                                       double* factor_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -245,14 +263,14 @@ __global__ void debug_occluder_kernel(KArgs a, int light, int self, const double
     FilterRay ffr = filter_origin(ip, a.scene_p1max);
     float occl = 1.0f;
     uint32_t c0 = 0, c1 = 0;
-    const int first = shadow_feeler<false, TREE, false>(a, geom, (cfdata_t)(const float*)a.fgeom, (cfdata_t)(const float*)a.ltab,
+    const int first = shadow_feeler<false, TREE, false, GRID>(a, geom, (cfdata_t)(const float*)a.fgeom, (cfdata_t)(const float*)a.ltab,
                                                  light, ffr, ip, fdir, self, false, occl, c0, c1);
     first_out[i] = first;
     factor_out[i] = occl;
 }
 
 // rt_debug_nearest: one lane per ray, the nearest-hit search exactly as the render kernel runs it.
-template <bool TREE>
+template <bool TREE, bool GRID>
 __global__ void debug_nearest_kernel(KArgs a, const double* rays, int n, int32_t* index_out, double* t_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -261,31 +279,39 @@ __global__ void debug_nearest_kernel(KArgs a, const double* rays, int n, int32_t
     double nearest = __builtin_inf();
     int cur = -1;
     uint32_t c0 = 0, c1 = 0;
-    find_nearest<false, TREE>(a, (cdata_t)(const double*)a.geom, (cfdata_t)(const float*)a.fgeom, o, d, nearest, cur, c0,
-                              c1);
+    // rays that start at the camera take the camera's grid when every ray of the wave does
+    const bool primary = (o.x == 0.0) & (o.y == 0.0) & (o.z == 0.0);
+    find_nearest<false, TREE, GRID>(a, (cdata_t)(const double*)a.geom, (cfdata_t)(const float*)a.fgeom, o, d, primary, nearest,
+                                    cur, c0, c1);
     index_out[i] = cur;
     t_out[i] = (cur >= 0) ? nearest : 0.0;
 }
 
-hipError_t launch_debug_nearest(const KArgs& a, bool tree, const double* rays, int n, int32_t* index_out, double* t_out,
-                                hipStream_t stream) {
+hipError_t launch_debug_nearest(const KArgs& a, bool tree, bool grid, const double* rays, int n, int32_t* index_out,
+                                double* t_out, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    const dim3 grid((n + 255) / 256), block(256);
-    if (tree) hipLaunchKernelGGL(debug_nearest_kernel<true>, grid, block, 0, stream, a, rays, n, index_out, t_out);
-    else hipLaunchKernelGGL(debug_nearest_kernel<false>, grid, block, 0, stream, a, rays, n, index_out, t_out);
+    if (grid && !a.grid_cells) return hipErrorInvalidValue;
+    const dim3 g((n + 255) / 256), block(256);
+    if (tree && grid) hipLaunchKernelGGL((debug_nearest_kernel<true, true>), g, block, 0, stream, a, rays, n, index_out, t_out);
+    else if (tree) hipLaunchKernelGGL((debug_nearest_kernel<true, false>), g, block, 0, stream, a, rays, n, index_out, t_out);
+    else if (grid) hipLaunchKernelGGL((debug_nearest_kernel<false, true>), g, block, 0, stream, a, rays, n, index_out, t_out);
+    else hipLaunchKernelGGL((debug_nearest_kernel<false, false>), g, block, 0, stream, a, rays, n, index_out, t_out);
     return hipGetLastError();
 }
 
-hipError_t launch_debug_occluder(const KArgs& a, bool tree, int light, int self, const double* points, int n,
+hipError_t launch_debug_occluder(const KArgs& a, bool tree, bool grid, int light, int self, const double* points, int n,
                                  int32_t* first_out, double* factor_out, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    const dim3 grid((n + 255) / 256), block(256);
-    if (tree)
-        hipLaunchKernelGGL(debug_occluder_kernel<true>, grid, block, 0, stream, a, light, self, points, n, first_out,
-                           factor_out);
+    if (grid && !a.grid_cells) return hipErrorInvalidValue;
+    const dim3 g((n + 255) / 256), block(256);
+    if (tree && grid)
+        hipLaunchKernelGGL((debug_occluder_kernel<true, true>), g, block, 0, stream, a, light, self, points, n, first_out, factor_out);
+    else if (tree)
+        hipLaunchKernelGGL((debug_occluder_kernel<true, false>), g, block, 0, stream, a, light, self, points, n, first_out, factor_out);
+    else if (grid)
+        hipLaunchKernelGGL((debug_occluder_kernel<false, true>), g, block, 0, stream, a, light, self, points, n, first_out, factor_out);
     else
-        hipLaunchKernelGGL(debug_occluder_kernel<false>, grid, block, 0, stream, a, light, self, points, n, first_out,
-                           factor_out);
+        hipLaunchKernelGGL((debug_occluder_kernel<false, false>), g, block, 0, stream, a, light, self, points, n, first_out, factor_out);
     return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@
         // ---- nearest hit, src/main.cc:37-47 ----
         int cur = -1;
         double nearest = __builtin_inf();
-        find_nearest<COUNT, TREE>(a, geom, fgeom, o, d, nearest, cur, c_sph, c_pln);
+        find_nearest<COUNT, TREE, GRID>(a, geom, fgeom, o, d, node == 1u, nearest, cur, c_sph, c_pln);
         RT_MARK("iter_tail");
         if (MW > 0 && level == 1) first_hit = cur;
 
@@ -66,7 +66,7 @@
                 float occl = 1.0f;
                 RT_EVENT(++c_feel);
                 RT_MARK("feeler_loop");
-                const int first = shadow_feeler<COUNT, TREE, LATE>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur,
+                const int first = shadow_feeler<COUNT, TREE, LATE, GRID>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur,
                                                              __double2hiint(gr2) < 0, occl, c_fex, c_pln);
                 RT_EVENT(if (first >= 0) ++c_occ);
                 RT_MARK("feeler_diffuse");

@@ -1,5 +1,8 @@
 """Kernel time of whole-frame renders, HIP events around n back-to-back launches.
-usage: [RT_LIB_OVERRIDE=path/to/lib.so] time_one.py [WORKLOAD ...]   (default: the headline workload)"""
+usage: [RT_LIB_OVERRIDE=path/to/lib.so] time_one.py [--depth D] [--flags F] [--no-lights] [WORKLOAD ...]
+(default: the headline workload; --depth / --flags / --no-lights vary the render: a ladder of
+such renders shows where a frame's time goes)"""
+import argparse
 import os
 import sys
 
@@ -13,11 +16,21 @@ if os.environ.get("RT_LIB_OVERRIDE"):
 import bench  # noqa: E402
 from raytracer_amd.device import DeviceTracer  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--depth", type=int, default=0)
+ap.add_argument("--flags", type=int, default=0)
+ap.add_argument("--no-lights", action="store_true")
+ap.add_argument("workloads", nargs="*")
+args = ap.parse_args()
+
 t = DeviceTracer(0)
-for name in (sys.argv[1:] or ["default_4k_d5"]):
+for name in (args.workloads or ["default_4k_d5"]):
     builder, w, h, d = bench.WORKLOADS[name]
     prims, lights = builder()
-    p = abi.make_params(w, h, d)
+    if args.no_lights:
+        lights = lights[:0]
+    p = abi.make_params(w, h, args.depth or d)
+    p["flags"] = args.flags
     n = 100 if name.startswith("default") else 4
     t.upload_scene(prims, lights)
     out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
@@ -27,7 +40,7 @@ for name in (sys.argv[1:] or ["default_4k_d5"]):
     torch.cuda.synchronize()
     best = 1e9
     tot = 0.0
-    reps = 5 if n > 4 else 1
+    reps = 5 if n > 4 else 2
     for _ in range(reps):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
@@ -39,4 +52,5 @@ for name in (sys.argv[1:] or ["default_4k_d5"]):
         ms = e0.elapsed_time(e1) / n
         best = min(best, ms)
         tot += ms
-    print(f"{os.path.basename(device.LIB_PATH)} {name}: mean {tot / reps:.4f} best {best:.4f} ms/frame", flush=True)
+    tag = f"{name} depth {args.depth or d} flags {args.flags}{' no lights' if args.no_lights else ''}"
+    print(f"{os.path.basename(device.LIB_PATH)} {tag}: mean {tot / reps:.4f} best {best:.4f} ms/frame", flush=True)
