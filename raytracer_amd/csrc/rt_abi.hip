@@ -483,7 +483,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         }
     }
     double tree_extent1 = 0.0;
-    std::vector<rt::FGeom> tree = rt::build_sphere_tree(tsph, &tree_extent1);
+    int tree_nodes = 0;
+    std::vector<rt::FGeom> tree = rt::build_sphere_tree(tsph, &tree_extent1, &tree_nodes);
     // the filter's per-ray error bound must cover the boxes too
     if (static_cast<float>(tree_extent1) * 1.0001f > p1max) p1max = static_cast<float>(tree_extent1) * 1.0001f;
     // anchor grids: the lights, then the camera (the origin, src/view_frustum.h:40).  Built for
@@ -545,7 +546,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
     RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_planes_before), planes_before.size() * sizeof(int32_t)));
     RT_HIP_TRY(ctx, hipMemcpy(ctx->d_planes_before, planes_before.data(), planes_before.size() * sizeof(int32_t),
                               hipMemcpyHostToDevice));
-    ctx->n_nodes = static_cast<int32_t>(tree.size());
+    ctx->n_nodes = tree_nodes;
     ctx->n_planes = static_cast<int32_t>(fplanes.size());
     RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->f_geom), fgeom.size() * sizeof(rt::FGeom)));
     RT_HIP_TRY(ctx, hipMemcpy(ctx->f_geom, fgeom.data(), fgeom.size() * sizeof(rt::FGeom), hipMemcpyHostToDevice));

@@ -35,26 +35,20 @@ inline float up(float v) { return std::nextafter(v, INFINITY); }
 inline void put_int(float& slot, int32_t v) { std::memcpy(&slot, &v, sizeof v); }
 
 // Node record, 32 bytes like FGeom (see whitted_device.h):
-//   interior  v[0..2] box centre, v[3..5] half extents, v[6] skip index (bits),
+//   interior  v[0..2] box centre, v[3..5] half extents, v[6] skip index (bits, > 0),
 //             v[7] smallest original index below the node (bits, >= 0)
+//   group     a box directly over 1..kLeafGroup spheres, whose leaf records follow it:
+//             as an interior node, but v[6] = -(number of leaves) (bits, < 0)
 //   leaf      v[0..2] sphere centre, v[3] radius^2 (as in the linear table),
 //             v[7] = ~index of the sphere in the caller's list (bits, < 0)
+// Leaves only ever follow a group node; the walk reads a group's leaves four at a time, so the
+// table ends with kLeafGroup - 1 spare records.
 // Returns the smallest original index below the node; *extent1 grows to |centre|_1 +
 // |half extents|_1 of the largest box (the filter's per-ray error bound needs it).
 inline int build(std::vector<TreeSphere>& s, int lo, int hi, std::vector<FGeom>& out, double* extent1) {
     const int self = static_cast<int>(out.size());
     out.emplace_back();
     std::memset(&out[self], 0, sizeof(FGeom));
-    if (hi - lo == 1) {
-        const TreeSphere& t = s[lo];
-        FGeom g;
-        std::memset(&g, 0, sizeof g);
-        for (int k = 0; k < 3; ++k) g.v[k] = static_cast<float>(t.c[k]);
-        g.v[3] = static_cast<float>(t.r * t.r);  // the filter allows for this rounding
-        put_int(g.v[7], ~t.index);
-        out[self] = g;
-        return t.index;
-    }
     // split at the median of the centres along the widest axis
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     double bmn[3] = {INFINITY, INFINITY, INFINITY}, bmx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -148,13 +142,23 @@ inline int build(std::vector<TreeSphere>& s, int lo, int hi, std::vector<FGeom>&
     if (hi - lo <= kLeafGroup) {
         // a box directly over up to kLeafGroup spheres: cheaper than two more levels of boxes
         min_index = s[lo].index;
-        for (int i = lo; i < hi; ++i) min_index = std::min(min_index, build(s, i, i + 1, out, extent1));
+        for (int i = lo; i < hi; ++i) {
+            const TreeSphere& t = s[i];
+            FGeom leaf;
+            std::memset(&leaf, 0, sizeof leaf);
+            for (int k = 0; k < 3; ++k) leaf.v[k] = static_cast<float>(t.c[k]);
+            leaf.v[3] = static_cast<float>(t.r * t.r);  // the filter allows for this rounding
+            put_int(leaf.v[7], ~t.index);
+            out.push_back(leaf);
+            min_index = std::min(min_index, t.index);
+        }
+        put_int(g.v[6], -(hi - lo));
     } else {
         const int min_l = build(s, lo, mid, out, extent1);
         const int min_r = build(s, mid, hi, out, extent1);
         min_index = std::min(min_l, min_r);
+        put_int(g.v[6], static_cast<int32_t>(out.size()));
     }
-    put_int(g.v[6], static_cast<int32_t>(out.size()));
     put_int(g.v[7], min_index);
     out[self] = g;
     return min_index;
@@ -162,14 +166,18 @@ inline int build(std::vector<TreeSphere>& s, int lo, int hi, std::vector<FGeom>&
 
 }  // namespace detail
 
-// Nodes in depth-first order; empty when there are no spheres.  *extent1 receives the
-// largest |centre|_1 + |half extents|_1 over the boxes (0 without interior nodes).
-inline std::vector<FGeom> build_sphere_tree(std::vector<TreeSphere> spheres, double* extent1) {
+// Nodes in depth-first order (followed by kLeafGroup - 1 spare records, not counted in
+// *n_nodes); empty when there are no spheres.  *extent1 receives the largest |centre|_1 +
+// |half extents|_1 over the boxes.
+inline std::vector<FGeom> build_sphere_tree(std::vector<TreeSphere> spheres, double* extent1, int* n_nodes) {
     std::vector<FGeom> out;
     *extent1 = 0.0;
+    *n_nodes = 0;
     if (spheres.empty()) return out;
-    out.reserve(2 * spheres.size());
+    out.reserve(2 * spheres.size() + detail::kLeafGroup);
     detail::build(spheres, 0, static_cast<int>(spheres.size()), out, extent1);
+    *n_nodes = static_cast<int>(out.size());
+    for (int i = 1; i < detail::kLeafGroup; ++i) out.push_back(out.back());
     return out;
 }
 

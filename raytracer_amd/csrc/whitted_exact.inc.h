@@ -512,7 +512,13 @@ __device__ __forceinline__ FNode load_node(cfdata_t p) {
     __asm__ volatile("" ::"s"(n.c0), "s"(n.c1), "s"(n.c2), "s"(n.h0), "s"(n.h1), "s"(n.h2), "s"(n.skip), "s"(n.tag));
     return n;
 }
-__device__ __forceinline__ unsigned long long box_miss(const FNode& n, const FilterRay& r) {
+// (C) nearest-hit walks only: the box lies beyond what the lane has found already - its
+//     smallest ray parameter, m . d - sum_j h_j |d_j| (same error bound as the largest),
+//     exceeds `reach`, an upper bound of the lane's `nearest` plus that error (near_reach()):
+//     every hit in the box has a larger t than the hit in hand (the reference's own rounding
+//     of t, at most 4e-8 |L| at a grazing hit, is within the bound's surplus of 5 U Sb).
+//     Pass reach = +inf to leave the condition out.
+__device__ __forceinline__ unsigned long long box_miss(const FNode& n, const FilterRay& r, float reach) {
     const F3 m = f3(n.c0, n.c1, n.c2) - r.o;
     const F3 d = r.d;
     const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
@@ -524,16 +530,35 @@ __device__ __forceinline__ unsigned long long box_miss(const FNode& n, const Fil
     const float sx = __builtin_fmaf(-n.h2, ay, __builtin_fmaf(-n.h1, az, cx));
     const float sy = __builtin_fmaf(-n.h0, az, __builtin_fmaf(-n.h2, ax, cy));
     const float sz = __builtin_fmaf(-n.h1, ax, __builtin_fmaf(-n.h0, ay, cz));
-    // largest ray parameter over the box, one chain of six
-    float tmax = m.x * d.x;
-    tmax = __builtin_fmaf(m.y, d.y, tmax);
-    tmax = __builtin_fmaf(m.z, d.z, tmax);
-    tmax = __builtin_fmaf(n.h0, ax, tmax);
-    tmax = __builtin_fmaf(n.h1, ay, tmax);
-    tmax = __builtin_fmaf(n.h2, az, tmax);
+    // largest and smallest ray parameter over the box
+    float md = m.x * d.x;
+    md = __builtin_fmaf(m.y, d.y, md);
+    md = __builtin_fmaf(m.z, d.z, md);
+    float ext = n.h0 * ax;
+    ext = __builtin_fmaf(n.h1, ay, ext);
+    ext = __builtin_fmaf(n.h2, az, ext);
     // one wave mask per condition: the lanes whose ray certainly misses the box
     return __builtin_amdgcn_ballot_w64(__builtin_fmaxf(__builtin_fmaxf(sx, sy), sz) > r.ecross) |
-           __builtin_amdgcn_ballot_w64(tmax < -r.ebehind);
+           __builtin_amdgcn_ballot_w64(md + ext < -r.ebehind) | __builtin_amdgcn_ballot_w64(md - ext > reach);
+}
+// Upper bound (float) of the lane's nearest hit so far, plus the error bound of a box's
+// smallest ray parameter.
+__device__ __forceinline__ float near_reach(double nearest, const FilterRay& r) {
+    return __builtin_fmaf((float)nearest, 1.0000002f, r.ebehind);
+}
+// The leaves of a group node: four records from `p` on (the table has spare records at its end).
+struct FLeaves {
+    FNode l[4];
+};
+__device__ __forceinline__ FLeaves load_leaves(cfdata_t p) {
+    FLeaves g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        g.l[j].c0 = p[8 * j]; g.l[j].c1 = p[8 * j + 1]; g.l[j].c2 = p[8 * j + 2]; g.l[j].h0 = p[8 * j + 3];
+        g.l[j].h1 = 0.0f; g.l[j].h2 = 0.0f; g.l[j].skip = 0;
+        g.l[j].tag = __float_as_int(p[8 * j + 7]);
+    }
+    return g;
 }
 
 // Nearest hit over all objects (src/main.cc:37-47) through the tree.  Objects are met in
@@ -577,16 +602,26 @@ __device__ __forceinline__ void find_nearest_tree(AT& a, cdata_t geom, const Fil
     const RT_CONST char* tree = (const RT_CONST char*)(const char*)a.tree;
     const uint32_t end = (uint32_t)a.n_nodes << 5;
     uint32_t off = 0;
+    float reach = near_reach(nearest, fr);
     while (off < end) {
         const FNode nd = load_node((cfdata_t)(tree + off));
         RT_ENTER(c_sph);  // (analysis builds: nodes visited)
         off += 32u;
-        if (nd.tag < 0) {  // leaf: the record is the sphere itself
-            near_candidate<COUNT>(nd, geom, ~nd.tag, fr, o, d, nearest, cur);
-            continue;
-        }
         const unsigned long long walking = __builtin_amdgcn_ballot_w64(true);
-        off = ((walking & ~box_miss(nd, fr)) != 0ull) ? off : (uint32_t)nd.skip << 5;
+        const bool enter = (walking & ~box_miss(nd, fr, reach)) != 0ull;
+        if (nd.skip < 0) {  // a group: its leaves follow, each a sphere
+            const uint32_t cnt = (uint32_t)(-nd.skip);
+            if (enter) {
+                const FLeaves lv = load_leaves((cfdata_t)(tree + off));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((uint32_t)j < cnt) near_candidate<COUNT>(lv.l[j], geom, ~lv.l[j].tag, fr, o, d, nearest, cur);
+                reach = near_reach(nearest, fr);
+            }
+            off += cnt << 5;
+        } else {
+            off = enter ? off : (uint32_t)nd.skip << 5;
+        }
     }
 }
 
@@ -635,14 +670,22 @@ __device__ __forceinline__ int find_occluder_tree(AT& a, cdata_t geom, const Fil
         const FNode nd = load_node((cfdata_t)(tree + off));
         RT_ENTER(c_nodes);  // (analysis builds: nodes visited)
         off += 32u;
-        if (nd.tag < 0) {
-            feeler_candidate(nd, geom, ~nd.tag, fr, ip, fdir, cur, best, pa, pb);
-            continue;
-        }
         // entered when some lane still looks for an index below the node's smallest and
         // its ray may touch the box
         const unsigned long long open = __builtin_amdgcn_ballot_w64(nd.tag < best);
-        off = ((open & ~box_miss(nd, fr)) != 0ull) ? off : (uint32_t)nd.skip << 5;
+        const bool enter = (open & ~box_miss(nd, fr, __builtin_inff())) != 0ull;
+        if (nd.skip < 0) {  // a group: its leaves follow
+            const uint32_t cnt = (uint32_t)(-nd.skip);
+            if (enter) {
+                const FLeaves lv = load_leaves((cfdata_t)(tree + off));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((uint32_t)j < cnt) feeler_candidate(lv.l[j], geom, ~lv.l[j].tag, fr, ip, fdir, cur, best, pa, pb);
+            }
+            off += cnt << 5;
+        } else {
+            off = enter ? off : (uint32_t)nd.skip << 5;
+        }
     }
     return best;
 }
@@ -914,15 +957,20 @@ __device__ __forceinline__ int shadow_feeler(AT& a, cdata_t geom, cfdata_t fgeom
     if (!GRID) return shadow_feeler_general<COUNT, TREE, LATE>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur, cur_plane, occl, c_sph, c_pln);
     int first = -1;
     bool ok;
+    RT_MARK("grid_cell");
     const GridList gl = grid_list(a, li, ffr.d, ok);
     ok = ok & (ffr.eray <= a.grid_eray_max);
     if (ok) {
         double pa = 0.0, pb = 0.0;  // see collides()
         int best = 0x7fffffff;
+        RT_MARK("grid_planes");
         feeler_planes(a, geom, ffr, ip, fdir, cur, best, pa, pb);
+        RT_MARK("grid_walk");
         find_occluder_grid(a, gl, ffr, ip, fdir, cur, best, pa, pb);
+        RT_MARK("grid_factor");
         first = (best != 0x7fffffff) ? best : -1;
         if (first >= 0) occl = occluder_factor(a.geom + first, ip, fdir, pa, pb);
+        RT_MARK("grid_tail");
 #ifndef RT_PHASE_PROFILE
         if (COUNT) count_feeler_tests(a, first, cur, cur_plane, c_sph, c_pln);
 #endif
