@@ -97,6 +97,11 @@ typedef struct rt_light {
                                  test the few spheres of one cell.  Used from 8 spheres on;
                                  the results are identical bit for bit with and without.  */
 #define RT_FLAG_GRID 32u      /* use the anchor grids whatever the scene size            */
+#define RT_FLAG_NOSKY 64u     /* trace every pixel.  Without it an image-only render of a
+                                 small scene first works out (on the host, once per
+                                 partition) which 8x8 tiles no primary ray can hit anything
+                                 in, and those tiles get the background colour
+                                 (src/main.cc:49-53) untraced; the image is the same.     */
 
 /*
  * Per-render parameters: the values the reference hard-wires in Tracer()/main()

@@ -25,6 +25,7 @@ RT_FLAG_TREE = 4
 RT_FLAG_PRUNE = 8
 RT_FLAG_NOGRID = 16
 RT_FLAG_GRID = 32
+RT_FLAG_NOSKY = 64
 
 PRIM_DTYPE = np.dtype(
     [

@@ -13,6 +13,7 @@
 #include <array>
 
 #include "anchor_grid.h"
+#include "sky_table.h"
 #include "sphere_tree.h"
 #include "whitted_device.h"
 
@@ -64,6 +65,15 @@ struct rt_ctx {
     std::map<void*, void*> queues;   // streams that only ever needed the tile queue (256 bytes)
     size_t workspace_bytes = 0;
     void* static_ws = nullptr;  // the library's built-in workspace on this device
+    // host copy of the scene and the screen bounds worked out from it (sky_table.h), kept per
+    // partition the context has rendered lately
+    std::vector<rt_prim> host_prims;
+    struct SkyEntry {
+        rt_params p;
+        rt::SkyTable t;
+    };
+    std::vector<SkyEntry> sky_cache;
+    size_t sky_next = 0;
     hipStream_t stream = nullptr;
     // rt_render / rt_render_node: second stream and events that let the copy of one part of
     // a frame run while the next part is rendered
@@ -237,6 +247,7 @@ int make_args(rt_ctx* ctx, const rt_params* p, rt::KArgs& a) {
     const double cmax = (0.5 * p->width + 1.0) * a.pw + (0.5 * p->height + 1.0) * a.ph;
     a.primary_in_range = (cmin >= 0x1p-370 && cmax <= 0x1p370) ? 1 : 0;
     a.prune = (p->flags & RT_FLAG_PRUNE) ? 1 : 0;
+    a.sky_unit_shift = rt::sky_unit_shift(p->width);
     return RT_OK;
 }
 
@@ -563,8 +574,33 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
     RT_HIP_TRY(ctx, hipMemcpy(ctx->d_lights, lt.data(), lt.size() * sizeof(rt::DLight), hipMemcpyHostToDevice));
     ctx->n_prims = n_prims;
     ctx->n_lights = n_lights;
+    ctx->host_prims.assign(prims, prims + n_prims);
+    ctx->sky_cache.clear();
     ctx->have_scene = true;
     return RT_OK;
+}
+
+// Screen bounds of the scene for the partition in `p` (image-only launches with one wave per
+// tile of scenes small enough that working them out costs less than they save); null = none.
+constexpr int kSkyMaxPrims = 64;
+constexpr size_t kSkyCacheEntries = 16;
+static const rt::SkyTable* sky_bounds(rt_ctx* ctx, const rt_params* p, const rt::KArgs& a) {
+    if (ctx->n_prims > kSkyMaxPrims || ctx->host_prims.empty()) return nullptr;
+    for (const rt_ctx::SkyEntry& e : ctx->sky_cache)
+        if (e.p.width == p->width && e.p.height == p->height && e.p.band_rows == p->band_rows &&
+            e.p.band_first == p->band_first && e.p.band_step == p->band_step && e.p.band_count == p->band_count &&
+            e.p.fov_deg == p->fov_deg)
+            return &e.t;
+    rt_ctx::SkyEntry e;
+    e.p = *p;
+    rt::build_sky_table(ctx->host_prims.data(), ctx->n_prims, *p, a.rows, a.pw, a.ph, &e.t);
+    if (ctx->sky_cache.size() < kSkyCacheEntries) {
+        ctx->sky_cache.push_back(e);
+        return &ctx->sky_cache.back().t;
+    }
+    ctx->sky_next = (ctx->sky_next + 1) % kSkyCacheEntries;
+    ctx->sky_cache[ctx->sky_next] = e;
+    return &ctx->sky_cache[ctx->sky_next].t;
 }
 
 // Enqueue one render with device outputs on `stream`; the deep-stack workspace is `ws` when
@@ -591,7 +627,10 @@ static int enqueue_render(rt_ctx* ctx, const rt_params* p, hipStream_t stream, v
                                    &deep_blocks)) != RT_OK)
             return rc;
     }
-    RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, tree, use_grid(ctx, p), deep_blocks, stream));
+    const rt::SkyTable* sky = nullptr;
+    if (!emit && !count && !tree && rt::stack_global_entries(a.max_depth) == 0 && !(p->flags & RT_FLAG_NOSKY))
+        sky = sky_bounds(ctx, p, a);
+    RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, tree, use_grid(ctx, p), deep_blocks, stream, sky));
     return RT_OK;
 }
 

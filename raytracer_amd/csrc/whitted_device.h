@@ -120,9 +120,21 @@ struct KArgs {
     int32_t grid_res;          // cells per face edge
     float grid_half;           // grid_res / 2
     float grid_eray_max;       // the grids hold for rays whose FilterRay::eray is at most this
+    int32_t sky_unit_shift;    // see SkyTable
     int32_t prune;             // ids, masks and counters describe the walk without the children of
                                // weight zero (the image-only kernels always leave those out)
 };
+
+// Screen bounds of the scene for launches with one wave per tile (sky_table.h): tile row ty reads
+// cols[min(ty, kSkyRows - 1)] = lo | hi << 8, the range of tile columns - in units of
+// 2^KArgs::sky_unit_shift tiles - outside of which no primary ray of that row hits anything.
+// Travels in the kernel-argument segment behind the KArgs; one independent scalar load per wave.
+constexpr int kSkyRows = 1024;
+struct SkyTable {
+    uint16_t cols[kSkyRows];
+};
+static_assert(sizeof(KArgs) % 8 == 0 && alignof(KArgs) == 8 && alignof(SkyTable) <= 8,
+              "the kernels find their arguments by offset in the kernel-argument segment: KArgs at 0, SkyTable behind it");
 
 // The walk keeps at most one pending refraction child per tree level 2..max_depth-1, 3.5 KB
 // per wave and entry.  Launches with a fixed grid (the tile queue): entry 0 (pushed by the
@@ -202,7 +214,9 @@ hipError_t static_workspace(int device, void** ptr);
 // `a` that are null are skipped), count = add event counts to a.counters.
 // grid = use the anchor grids (a.grid_cells must be set).
 // deep_blocks: grid of a deep-stack launch (deep_grid_blocks), ignored otherwise.
-hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, bool grid, int deep_blocks, hipStream_t stream);
+// sky = screen bounds for an image-only launch with one wave per tile, null = none.
+hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, bool grid, int deep_blocks, hipStream_t stream,
+                          const SkyTable* sky = nullptr);
 
 
 // Enqueue the nearest-hit hook (rt_debug_nearest); only the scene fields of `a` are read.

@@ -69,7 +69,7 @@ __device__ __forceinline__ double* wave_gstack(AT& a, size_t w) {
 // Without the deep stack the grid holds one wave per 8x8 tile of the strip; with it the grid
 // is fixed and its waves take pixels from the tile queue (TileQueue).
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, bool GRID>
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? image_waves(GRID) : 3, (MW == 0 && !COUNT && image_waves(GRID) > 4) ? image_waves(GRID) : 4))) void whitted_kernel(KArgs a_) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((MW == 0 && !COUNT) ? image_waves(GRID) : 3, (MW == 0 && !COUNT && image_waves(GRID) > 4) ? image_waves(GRID) : 4))) void whitted_kernel(KArgs a_, SkyTable) {
     extern __shared__ double lds_stack[];
     const KArgs& a = a_;
     const int lane = threadIdx.x & 63;
@@ -89,21 +89,34 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         const int ty = blockIdx.y;
         const int x = tx * kTile + (lane & 7);
         const int k = ty * kTile + (lane >> 3);  // row in strip order
+        if (MW == 0 && !COUNT) {
+            // a tile outside the screen bounds of the scene is background (src/main.cc:49-53)
+            const RT_CONST uint32_t* sky =
+                (const RT_CONST uint32_t*)((const RT_CONST char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(KArgs));
+            const uint32_t row = min((uint32_t)ty, (uint32_t)(kSkyRows - 1));
+            const uint32_t rng = sky[row >> 1] >> ((row & 1u) << 4);
+            const uint32_t col = (uint32_t)tx >> a.sky_unit_shift;
+            if (col < (rng & 0xffu) || col > ((rng >> 8) & 0xffu)) {
+                const uint32_t none[1] = {0};
+                if ((x < a.width) && (k < a.rows)) store_pixel<0>(a, x, k, a.bgr_c[0], a.bgr_c[1], a.bgr_c[2], -1, none, none);
+                return;
+            }
+        }
         trace_tile<MW, COUNT, TREE, DEEP, LATE, GRID>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
     }
     flush_counters<COUNT>(a, cnt, lane);
 }
 
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, bool GRID>
-static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t stream) {
+static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t stream, const SkyTable& sky) {
     const int bx = (a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     if (bx <= 0 || a.tiles_y <= 0) return hipSuccess;
     const size_t lds = DEEP ? stack_lds_bytes(a.max_depth) : tile_stack_lds_bytes(a.max_depth);
     if (DEEP || TREE) {
         if (deep_blocks < 1 || deep_blocks > (DEEP ? kDeepMaxBlocks : kQueueMaxBlocks) || !a.tile_queue || (DEEP && !a.gstack)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE, GRID>), dim3(deep_blocks), dim3(64 * kWavesPerBlock), lds, stream, a);
+        hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE, GRID>), dim3(deep_blocks), dim3(64 * kWavesPerBlock), lds, stream, a, sky);
     } else {
-        hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE, GRID>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a);
+        hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE, GRID>), dim3(bx, a.tiles_y), dim3(64 * kWavesPerBlock), lds, stream, a, sky);
     }
     return hipGetLastError();
 }
@@ -182,42 +195,47 @@ hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, bool grid, in
 // The late-predicate shadow loop exists for the image-only kernel without the tree only; a
 // launch that uses the anchor grids has no use for it.
 template <int MW, bool COUNT, bool TREE, bool DEEP>
-static hipError_t launch_ttd(const KArgs& a, bool grid, int deep_blocks, hipStream_t stream) {
+static hipError_t launch_ttd(const KArgs& a, bool grid, int deep_blocks, hipStream_t stream, const SkyTable& sky) {
     if (grid) {
         if (!a.grid_cells || !a.grid_entries) return hipErrorInvalidValue;
-        return launch_ttdl<MW, COUNT, TREE, DEEP, false, true>(a, deep_blocks, stream);
+        return launch_ttdl<MW, COUNT, TREE, DEEP, false, true>(a, deep_blocks, stream, sky);
     }
     if (MW == 0 && !COUNT && !TREE && a.n_lights >= kLateMinLights)
-        return launch_ttdl<MW, COUNT, TREE, DEEP, (MW == 0 && !COUNT && !TREE), false>(a, deep_blocks, stream);
-    return launch_ttdl<MW, COUNT, TREE, DEEP, false, false>(a, deep_blocks, stream);
+        return launch_ttdl<MW, COUNT, TREE, DEEP, (MW == 0 && !COUNT && !TREE), false>(a, deep_blocks, stream, sky);
+    return launch_ttdl<MW, COUNT, TREE, DEEP, false, false>(a, deep_blocks, stream, sky);
 }
 
 template <int MW, bool COUNT, bool TREE>
-static hipError_t launch_tt(const KArgs& a, bool grid, int deep_blocks, hipStream_t stream) {
-    if (stack_global_entries(a.max_depth) == 0) return launch_ttd<MW, COUNT, TREE, false>(a, grid, deep_blocks, stream);
-    return launch_ttd<MW, COUNT, TREE, true>(a, grid, deep_blocks, stream);
+static hipError_t launch_tt(const KArgs& a, bool grid, int deep_blocks, hipStream_t stream, const SkyTable& sky) {
+    if (stack_global_entries(a.max_depth) == 0) return launch_ttd<MW, COUNT, TREE, false>(a, grid, deep_blocks, stream, sky);
+    return launch_ttd<MW, COUNT, TREE, true>(a, grid, deep_blocks, stream, sky);
 }
 
 template <int MW, bool COUNT>
-static hipError_t launch_t(const KArgs& a, bool tree, bool grid, int deep_blocks, hipStream_t stream) {
-    return tree ? launch_tt<MW, COUNT, true>(a, grid, deep_blocks, stream) : launch_tt<MW, COUNT, false>(a, grid, deep_blocks, stream);
+static hipError_t launch_t(const KArgs& a, bool tree, bool grid, int deep_blocks, hipStream_t stream, const SkyTable& sky) {
+    return tree ? launch_tt<MW, COUNT, true>(a, grid, deep_blocks, stream, sky) : launch_tt<MW, COUNT, false>(a, grid, deep_blocks, stream, sky);
 }
 
-hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, bool grid, int deep_blocks, hipStream_t stream) {
+hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, bool grid, int deep_blocks, hipStream_t stream,
+                          const SkyTable* sky_in) {
     const int mw = emit ? a.mask_words : 0;
+    SkyTable all;
+    if (!sky_in)
+        for (int i = 0; i < kSkyRows; ++i) all.cols[i] = 0xff00u;  // every column of every row
+    const SkyTable& sky = sky_in ? *sky_in : all;
     if (count) {
         switch (mw) {
-            case 0: return launch_t<0, true>(a, tree, grid, deep_blocks, stream);
-            case 1: return launch_t<1, true>(a, tree, grid, deep_blocks, stream);
-            case 2: return launch_t<2, true>(a, tree, grid, deep_blocks, stream);
-            case 4: return launch_t<4, true>(a, tree, grid, deep_blocks, stream);
+            case 0: return launch_t<0, true>(a, tree, grid, deep_blocks, stream, sky);
+            case 1: return launch_t<1, true>(a, tree, grid, deep_blocks, stream, sky);
+            case 2: return launch_t<2, true>(a, tree, grid, deep_blocks, stream, sky);
+            case 4: return launch_t<4, true>(a, tree, grid, deep_blocks, stream, sky);
         }
     } else {
         switch (mw) {
-            case 0: return launch_t<0, false>(a, tree, grid, deep_blocks, stream);
-            case 1: return launch_t<1, false>(a, tree, grid, deep_blocks, stream);
-            case 2: return launch_t<2, false>(a, tree, grid, deep_blocks, stream);
-            case 4: return launch_t<4, false>(a, tree, grid, deep_blocks, stream);
+            case 0: return launch_t<0, false>(a, tree, grid, deep_blocks, stream, sky);
+            case 1: return launch_t<1, false>(a, tree, grid, deep_blocks, stream, sky);
+            case 2: return launch_t<2, false>(a, tree, grid, deep_blocks, stream, sky);
+            case 4: return launch_t<4, false>(a, tree, grid, deep_blocks, stream, sky);
         }
     }
     return hipErrorInvalidValue;

@@ -105,6 +105,91 @@ def test_random_spheres_4k_rows(tracer):
     assert_parity(dev, ora, "1024 spheres 4K rows")
 
 
+def test_glass_4k_depth8_rows(tracer):
+    """The glass benchmark frame at its full size (the fixed grid of 1280 blocks with the
+    deep-stack workspace) checked against the checker on strided rows."""
+    prims, lights = scenes.glass_scene()
+    p = abi.make_params(3840, 2160, 8, band_rows=1, band_first=5, band_step=135, band_count=16)
+    assert abi.strip_rows(p) == 16
+    tracer.upload_scene(prims, lights)
+    dev = tracer.render(p, want_counters=True)
+    ora = oracle_lib.render(prims, lights, p, want_counters=True)
+    assert_parity(dev, ora, "glass 4K D8 rows")
+    # the whole frame through the image-only kernel: its rows equal the strip's
+    import torch
+
+    full = abi.make_params(3840, 2160, 8)
+    out = torch.zeros((2160, 3840, 3), dtype=torch.uint8, device="cuda")
+    tracer.render_device(full, torch.cuda.current_stream().cuda_stream, out.data_ptr())
+    torch.cuda.synchronize()
+    rows = abi.strip_image_rows(p)
+    assert np.array_equal(out.cpu().numpy()[rows], dev["bgr"])
+
+
+def test_many_lights_saturated(tracer):
+    """256 bright lights (the library's limit): the diffuse sum runs far past 1.0, so the
+    single-precision accumulation, the clamp and the 8-bit conversion are exercised at the top
+    of the range; and dim ones, where 256 small terms add up."""
+    for inten, what in ((0.9, "bright"), (0.004, "dim")):
+        prims, lights = scenes.glass_scene(n_spheres=10, n_lights=256, seed=0x256)
+        lights = lights.copy()
+        lights["intensity"] = scenes.f32(inten)
+        p = abi.make_params(96, 64, 5)
+        dev, ora = _both(tracer, prims, lights, p)
+        assert_parity(dev, ora, f"256 lights {what}")
+        if what == "bright":
+            assert (ora["bgr"] == 255).mean() > 0.2
+
+
+@pytest.mark.parametrize("name", ["default", "orbit", "inside", "tilted_planes", "glass", "no_objects_in_view"])
+def test_screen_bounds(tracer, name):
+    """Image-only renders of small scenes skip the tiles no primary ray can hit anything in
+    (screen bounds worked out on the host): the frame equals the one traced pixel by pixel
+    (RT_FLAG_NOSKY), whole and as strips of every shape, at widths with and without dword rows."""
+    if name == "default":
+        prims, lights = scenes.default_scene()
+    elif name == "orbit":
+        prims, lights = scenes.orbit_scene(*scenes.default_scene(), 2.2)
+    elif name == "inside":
+        prims, lights = scenes.default_scene()
+        prims = prims.copy()
+        prims[1]["p"] = (0.0, 0.0, 0.5)   # the camera inside a sphere
+    elif name == "tilted_planes":
+        k = (0.6, 0.6, 0.6)
+        prims = scenes._stack([
+            scenes.plane((0, -3, 0), (0.1, 1, 0.05), k, reflectivity=0.3),
+            scenes.plane((-8, 0, 0), (1, 0.05, 0.1), (0.8, 0.3, 0.3), reflectivity=0.5),
+            scenes.plane((0, 0, -1), (0, 0, 1), k, reflectivity=0.0),      # behind the camera, facing it
+            scenes.sphere((3, 4, 16), 1.5, (0.9, 0.8, 0.2), reflectivity=1.0),
+            scenes.sphere((-30, 20, 40), 2.0, (0.2, 0.8, 0.2)),             # far off axis
+            scenes.sphere((0, 0, -5), 1.0, (0.2, 0.2, 0.9)),                # behind the camera
+        ], abi.PRIM_DTYPE)
+        lights = scenes._stack([scenes.point_light((1, 1, 1), 0.6, (0, 8, 10))], abi.LIGHT_DTYPE)
+    elif name == "glass":
+        prims, lights = scenes.glass_scene(n_spheres=7, n_lights=2)
+    else:
+        prims, lights = scenes.default_scene()
+        prims = prims.copy()
+        prims["p"] = prims["p"] * np.array([1.0, 1.0, -1.0])  # everything behind the camera
+    tracer.upload_scene(prims, lights)
+    shapes = [
+        abi.make_params(200, 117, 5),
+        abi.make_params(203, 64, 4),                                             # rows that do not start on a dword
+        abi.make_params(640, 360, 5, band_rows=8, band_first=1, band_step=3, band_count=15),
+        abi.make_params(640, 360, 3, band_rows=1, band_first=0, band_step=7, band_count=52),
+        abi.make_params(640, 360, 5, band_rows=5, band_first=2, band_step=4, band_count=18),
+        abi.make_params(1920, 1080, 2),
+        abi.make_params(64, 9000, 2),                                            # more tile rows than the table holds
+    ]
+    skipped = 0
+    for p in shapes:
+        fast = tracer.render(p, want_ids=False, want_masks=False)["bgr"]
+        slow = tracer.render(_with_flags(p, abi.RT_FLAG_NOSKY), want_ids=False, want_masks=False)["bgr"]
+        assert np.array_equal(fast, slow), (name, int(p["width"]), int(p["band_rows"]))
+        skipped += int((fast == fast[-1, 0]).all(axis=-1).sum())
+    assert skipped > 0 or name == "inside"
+
+
 def test_glass_depth8(tracer):
     prims, lights = scenes.glass_scene()
     p = abi.make_params(128, 72, 8)
@@ -148,6 +233,16 @@ def test_plane_box(tracer):
     assert int(ora["counters"]["feelers_occluded"]) > 0
 
 
+# Every way the kernels search the objects: container-order loop or sphere tree, each with and
+# without the anchor grids (per light and for the camera: the spheres of one cell of lines).
+OBJECT_LOOP_MODES = (
+    abi.RT_FLAG_LINEAR | abi.RT_FLAG_NOGRID,
+    abi.RT_FLAG_TREE | abi.RT_FLAG_NOGRID,
+    abi.RT_FLAG_LINEAR | abi.RT_FLAG_GRID,
+    abi.RT_FLAG_TREE | abi.RT_FLAG_GRID,
+)
+
+
 def _with_flags(p, flags):
     q = p.copy()
     q["flags"] = flags
@@ -170,13 +265,16 @@ def test_sphere_tree_equals_container_order(tracer, name):
         prims, lights = scenes.glass_scene(n_spheres=1, n_lights=2)
     p = abi.make_params(128, 96, 6)
     tracer.upload_scene(prims, lights)
-    tree = tracer.render(_with_flags(p, abi.RT_FLAG_TREE), want_counters=True)
-    lin = tracer.render(_with_flags(p, abi.RT_FLAG_LINEAR), want_counters=True)
+    tree = tracer.render(_with_flags(p, abi.RT_FLAG_TREE | abi.RT_FLAG_NOGRID), want_counters=True)
     ora = oracle_lib.render(prims, lights, p, want_counters=True)
     assert_parity(tree, ora, f"tree {name}")
-    for k in ("bgr", "hit_id", "hit_mask", "spawn_mask"):
-        assert np.array_equal(tree[k], lin[k]), k
-    assert tree["counters"] == lin["counters"]
+    for mode in OBJECT_LOOP_MODES:
+        other = tracer.render(_with_flags(p, mode), want_counters=True)
+        for k in ("bgr", "hit_id", "hit_mask", "spawn_mask"):
+            assert np.array_equal(tree[k], other[k]), (k, mode)
+        assert tree["counters"] == other["counters"], mode
+        image = tracer.render(_with_flags(p, mode), want_ids=False, want_masks=False)
+        assert np.array_equal(image["bgr"], tree["bgr"]), mode
 
 
 def test_sphere_tree_ties_and_first_occluder(tracer):
@@ -290,7 +388,7 @@ def test_shadow_feeler_grazing(tracer, name):
         pts = np.concatenate([pts, rng.uniform(-8, 8, (2000, 3)) + np.array([0.0, 2.0, 14.0])])
         for self_index in (-1, 0, 1):
             f_o, k_o = oracle_lib.occluder(prims, lights, light, self_index, pts)
-            for flags in (abi.RT_FLAG_LINEAR, abi.RT_FLAG_TREE):
+            for flags in OBJECT_LOOP_MODES:
                 f_d, k_d = tracer.debug_occluder(pts, light, self_index, flags)
                 bad = np.nonzero(f_d != f_o)[0]
                 assert bad.size == 0, f"{name} light {light} self {self_index} flags {flags}: {bad[:5]} {f_d[bad[:5]]} {f_o[bad[:5]]}"
@@ -299,15 +397,18 @@ def test_shadow_feeler_grazing(tracer, name):
         assert (f_o >= 0).any() and (f_o < 0).any()
 
 
-def _grazing_rays(prims, rng, per_sphere=300):
-    """Unit rays from random origins that pass a sphere's silhouette within a relative
-    1e-16 .. 1e-3, half of them pointing away from it, plus rays grazing the planes."""
+def _grazing_rays(prims, rng, per_sphere=300, origin=None):
+    """Unit rays from random origins (or all from `origin`) that pass a sphere's silhouette
+    within a relative 1e-16 .. 1e-3, half of them pointing away from it, plus rays grazing the
+    planes."""
     rays = []
     for pr in prims:
         if pr["type"] != abi.RT_PRIM_SPHERE:
             continue
         c, r = np.asarray(pr["p"], dtype=np.float64), float(pr["q"][0])
         o = c + rng.normal(size=(per_sphere, 3)) * rng.choice([2.0, 8.0, 300.0, 2e4], (per_sphere, 1)) * max(r, 1.0)
+        if origin is not None:
+            o = np.tile(np.asarray(origin, dtype=np.float64), (per_sphere, 1))
         w = c - o
         dist = np.linalg.norm(w, axis=1, keepdims=True)
         ok = (dist[:, 0] > 1.01 * r)
@@ -325,6 +426,8 @@ def _grazing_rays(prims, rng, per_sphere=300):
         d[1::4] *= -1.0  # a quarter away from it: only what lies behind may be hit
         rays.append(np.concatenate([o, d], axis=1))
     out = np.concatenate(rays)
+    if origin is not None:
+        return out
     # rays almost parallel to the floor plane y = -3, from just above and just below it
     m = 2000
     o = np.stack([rng.uniform(-20, 20, m), -3 + rng.choice([-1, 1], m) * 10.0 ** rng.uniform(-9, 0, m), rng.uniform(0, 40, m)], 1)
@@ -349,8 +452,12 @@ def test_nearest_hit_grazing(tracer, name):
         prims = np.concatenate([prims, prims[1:]])
     tracer.upload_scene(prims, lights)
     rays = _grazing_rays(prims, np.random.default_rng(7), per_sphere=300 if name != "spheres200" else 60)
+    # the same kind of rays from the camera (origin exactly zero): these take the camera's anchor grid
+    cam = _grazing_rays(prims, np.random.default_rng(8), per_sphere=300 if name != "spheres200" else 60, origin=(0.0, 0.0, 0.0))
+    cam = cam[: len(cam) // 64 * 64]  # whole waves of camera rays
+    rays = np.concatenate([cam, rays])
     i_o, t_o = oracle_lib.nearest(prims, rays)
-    for flags in (abi.RT_FLAG_LINEAR, abi.RT_FLAG_TREE):
+    for flags in OBJECT_LOOP_MODES:
         i_d, t_d = tracer.debug_nearest(rays, flags)
         bad = np.nonzero(i_d != i_o)[0]
         assert bad.size == 0, f"{name} flags {flags}: rays {bad[:5]} device {i_d[bad[:5]]} checker {i_o[bad[:5]]}"
@@ -491,7 +598,7 @@ def test_random_materials_depths_and_modes(tracer, seed):
     prims["reflectivity"], prims["transparency"] = r, t
     depth = int(rng.integers(2, 9))
     w, h = int(rng.integers(20, 90)), int(rng.integers(20, 70))
-    for mode in (abi.RT_FLAG_LINEAR, abi.RT_FLAG_TREE):
+    for mode in OBJECT_LOOP_MODES:
         p = abi.make_params(w, h, depth)
         p["flags"] = mode
         dev, ora = _both(tracer, prims, lights, p)

@@ -52,3 +52,39 @@ def test_static_workspace_render_equals_allocating_render(tracer):
     stream.synchronize()
     for x, y in zip(a, b):
         assert np.array_equal(x.cpu().numpy(), y.cpu().numpy())
+
+
+def test_static_entry_allocates_nothing(tracer):
+    """What the entry point is for: on a stream the context has never seen, renders that need a
+    workspace (depth 8; a sphere-tree scene at depth 5, which needs the tile queue only, and at
+    depth 8) leave the device's free memory exactly as it was, and give the frames of the
+    allocating entry point."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    cases = [
+        (scenes.glass_scene(), abi.make_params(256, 144, 8)),
+        (scenes.random_spheres_scene(48, 3, seed=0x48), abi.make_params(256, 144, 5)),
+        (scenes.random_spheres_scene(48, 3, seed=0x48), abi.make_params(256, 144, 8)),
+    ]
+    for (prims, lights), p in cases:
+        tracer.upload_scene(prims, lights)
+        h, w = abi.strip_rows(p), int(p["width"])
+        out_s = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+        out_a = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+        fresh = torch.cuda.Stream()       # the context has no workspace for this stream, and never gets one here
+        # (the first launch on a new stream lets the HIP runtime set up the stream's queue, its
+        # private-memory arena included: that is not the library's doing and is kept out of the count)
+        tracer.render_device_static(p, fresh.cuda_stream, out_s.data_ptr())
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        out_s.zero_()
+        tracer.render_device_static(p, fresh.cuda_stream, out_s.data_ptr())
+        tracer.render_device_static(p, fresh.cuda_stream, out_s.data_ptr())
+        fresh.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before, "rt_render_device_static changed the free device memory"
+        tracer.render_device(p, fresh.cuda_stream, out_a.data_ptr())
+        fresh.synchronize()
+        assert np.array_equal(out_s.cpu().numpy(), out_a.cpu().numpy())
+        assert int(out_s.max().item()) > 0
+    tracer.trim()
