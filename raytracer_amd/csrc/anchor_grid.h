@@ -43,6 +43,7 @@ struct GridSphere {
     double c[3];
     double r2;       // radius^2 as the reference computes it
     int32_t index;   // position in the caller's object list; the input is ascending in it
+    float transparency;
 };
 
 struct AnchorGrids {
@@ -52,18 +53,34 @@ struct AnchorGrids {
     std::vector<GridEntry> entries;
 };
 
-// The constants of the light-anchored line test for the sphere (centre - anchor = L, r2):
-// L in float and thr = |L|^2 - r^2 - 20 U |L|_1^2 rounded down (see line_miss_from_light()).
-inline void line_test_record(const double L[3], double r2, float out[4]) {
+// The constants of the light-anchored tests for the sphere (centre - anchor = L, r2) - see
+// line_miss_from_light() and classify_sphere() in whitted_exact.inc.h (U = 6e-8 >= 2^-24):
+//   out[0..2] L in float
+//   out[3]    thr  = |L|^2 - r^2 - 24 U |L|_1^2, rounded down: the float value of thr - (L.d)^2 is
+//             off by at most 21.3 U |L|_1^2 for a direction within 6 U of the true one
+//   cold[0]   r^2 in float
+//   cold[1]   ehit = bound on the error of r^2 - |L - (L.d) d|^2 evaluated in float, for lines
+//             that pass within sqrt(r^2 + 50 U |L|_1^2) of the centre (all that thr lets through):
+//             |P~ - P| <= 19.1 U |L|_1, so the squared length is off by at most
+//             38.2 U rr |L|_1 + 365 U^2 |L|_1^2 + 3 U rr^2, plus U r^2 for cold[0]; stored with
+//             a factor 1.5 to spare
+inline void line_test_record(const double L[3], double r2, float out[4], float* cold = nullptr) {
+    const double U = 6.0e-8;
     double n2 = 0.0, n1 = 0.0;
     for (int c = 0; c < 3; ++c) {
         n2 += L[c] * L[c];
         n1 += std::fabs(L[c]);
         out[c] = static_cast<float>(L[c]);
     }
-    const double thr = n2 - r2 - 20.0 * 6.0e-8 * n1 * n1;
+    const double thr = n2 - r2 - 24.0 * U * n1 * n1;
     float tf = static_cast<float>(thr);
     out[3] = std::nextafter(std::nextafter(tf, -INFINITY), -INFINITY);
+    if (cold) {
+        const double rr = std::sqrt(r2 + 50.0 * U * n1 * n1);
+        const double ehit = 1.5 * (38.2 * U * rr * n1 + 365.0 * U * U * n1 * n1 + 3.0 * U * rr * rr + U * r2);
+        cold[0] = static_cast<float>(r2);
+        cold[1] = std::nextafter(static_cast<float>(ehit), INFINITY);
+    }
 }
 
 namespace detail {
@@ -173,11 +190,14 @@ inline bool build_anchor_grids(const std::vector<GridSphere>& spheres, const std
             const double L[3] = {s.c[0] - anchors[ai][0], s.c[1] - anchors[ai][1], s.c[2] - anchors[ai][2]};
             GridEntry e;
             std::memset(&e, 0, sizeof e);
-            float rec[4];
-            line_test_record(L, s.r2, rec);
+            float rec[4], cold[2];
+            line_test_record(L, s.r2, rec, cold);
             e.l[0] = rec[0]; e.l[1] = rec[1]; e.l[2] = rec[2];
             e.thr = rec[3];
             e.index = s.index;
+            e.r2 = cold[0];
+            e.ehit = cold[1];
+            e.transparency = s.transparency;
             for (int v = f.v0; v <= f.v1; ++v)
                 for (int u = f.u0; u <= f.u1; ++u) {
                     const size_t ci = (static_cast<size_t>(f.face) * res + v) * res + u;

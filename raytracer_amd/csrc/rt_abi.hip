@@ -472,6 +472,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         if (s.type == RT_PRIM_PLANE) {
             rt::FGeom g = fgeom[i];
             std::memcpy(&g.v[6], &i, sizeof(int32_t));
+            g.v[7] = static_cast<float>(s.transparency);
             fplanes.push_back(g);
         } else {
             tsph.push_back(rt::TreeSphere{{s.p[0], s.p[1], s.p[2]}, std::fabs(s.q[0]), i});
@@ -505,7 +506,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         std::vector<rt::GridSphere> gs;
         gs.reserve(tsph.size());
         for (const rt::TreeSphere& t : tsph)
-            gs.push_back(rt::GridSphere{{t.c[0], t.c[1], t.c[2]}, prims[t.index].q[0] * prims[t.index].q[0], t.index});
+            gs.push_back(rt::GridSphere{{t.c[0], t.c[1], t.c[2]}, prims[t.index].q[0] * prims[t.index].q[0], t.index,
+                                        static_cast<float>(prims[t.index].transparency)});
         std::vector<std::array<double, 3>> anchors;
         for (int li = 0; li < n_lights; ++li) anchors.push_back({lights[li].pos[0], lights[li].pos[1], lights[li].pos[2]});
         anchors.push_back({0.0, 0.0, 0.0});

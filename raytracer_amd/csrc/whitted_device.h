@@ -72,7 +72,8 @@ struct GridEntry {
     float l[3];              // sphere centre - anchor
     float thr;               // threshold of the light-anchored line test (line_miss_from_light)
     int32_t index;           // the sphere's position in the caller's object list
-    int32_t pad[3];
+    float r2, ehit;          // classify_sphere(): radius^2 and the error bound of the hit test
+    float transparency;      // what the sphere lets through as an occluder (src/objects.h:44)
 };
 static_assert(sizeof(GridCell) == 8 && sizeof(GridEntry) == 32, "record size");
 

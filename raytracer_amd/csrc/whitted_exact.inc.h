@@ -763,11 +763,155 @@ __device__ __forceinline__ void find_nearest_grid(AT& a, GridList gl, const Filt
     }
 }
 
+constexpr int kGroup = 4;  // the object loops take the scene four records at a time
+
+// ---- certified single-precision shadow feelers -------------------------------------------
+// A shadow feeler only asks WHETHER each object is hit, in container order, until the first one
+// is (src/objects.h:35-46); the hit parameter of that first occluder only feeds a colour.  So a
+// feeler can be answered in single precision wherever the answer is certain: a float test that
+// proves "the reference's TestCollision returns nullopt" (certain miss) or "returns a value"
+// (certain hit).  Only a lane that meets an object for which neither can be proved (a line
+// that grazes a silhouette within the float error, an origin on a surface) stops and is sent
+// through the double-precision search; its colour then comes from there.  Which path a lane
+// takes depends on its own ray only, so a pixel does not depend on its neighbours.
+//
+// The direction is normalised in float: d~ = v~ rsq(v~.v~), v~ = float(P - ip) (the
+// subtraction in double).  With U = 2^-24: |d~ - d| <= 6U (v~: U, the squared length: 3U,
+// v_rsq_f32: 1 ulp, the products: U), the length is within 5U of 1, dist~ = (v~.v~) rsq is
+// within 8U |P - ip| of the distance to the light.
+//   sphere, L = c - P from the host (float, error U):  t = L~.d~ is within 10.1 U |L|_1 of L.d.
+//     line test (line_miss_from_light): thr - t^2 > eray proves the miss (thr holds 24 U |L|_1^2).
+//     Otherwise P~ = L~ - t d~ is the perpendicular from the line to the centre, x = r^2 - |P~|^2
+//     is within `ehit` (host, see line_test_record()) of the true r^2 - D^2:
+//       x < -(ehit + 32 eray)         certain miss   (eray: the reference's own rounding of d2)
+//       tca~ = t + dist~ < -efront    certain miss   (tca~ is within efront = 16 U (Sb + dist~) of
+//                                                     the reference's tca; it returns for tca < 0)
+//       x > khit + 32 eray and tca~ > efront   certain hit; khit = ehit for an opaque sphere (its
+//         factor is zero whatever the hit point), 64 ehit for a transparent one, which keeps the
+//         error of thc = sqrt(x) below sqrt(ehit) / 16.  Its factor needs the normal at the hit
+//         point: -dot(normal, d) = +thc / r at the near root, -thc / r at the far root, and the
+//         reference takes the far root iff tca < thc (src/objects.h:132-136), i.e.
+//         w = tca^2 - x < 0; |w~ - w| <= efront (2 tca~ + efront) + ehit, inside that band the lane
+//         is not certain either.
+//   plane (unit normal n, h = p0.n): denom~ = d~.n~ within eden = 12U, num~ = h~ - o~.n~ within
+//     en = 6U |o|_1 + herr.  With |num~| > en: |denom~| > eden and opposite signs is a certain
+//     miss (t < 0); |denom~| > 1e-6 (1 + 1e-5) + eden and equal signs a certain hit
+//     (src/objects.h:93-100); its factor is -denom~ (the normal does not depend on the hit point).
+struct FeelRay {
+    F3 o;          // float image of the hit point
+    F3 d;          // d~
+    float dist;    // dist~
+    float en_ray;  // 6U |o|_1
+    float eray;    // 1e-13 Sb^2
+    float efront;  // 16 U (Sb + dist~)
+    bool valid;    // the squared length is in the range in which the float normalisation keeps
+                   // its error bound (false also for a NaN): otherwise the lane is not certain
+};
+__device__ __forceinline__ FeelRay feel_ray(V3 ip, V3 to_light, float scene_p1max) {
+    const float U = 6.0e-8f;
+    FeelRay r;
+    r.o = f3((float)ip.x, (float)ip.y, (float)ip.z);
+    const F3 v = f3((float)to_light.x, (float)to_light.y, (float)to_light.z);
+    const float s2 = dotf(v, v);
+    const float inv = __builtin_amdgcn_rsqf(s2);
+    r.d = f3(v.x * inv, v.y * inv, v.z * inv);
+    r.dist = s2 * inv;
+    r.valid = (s2 > 1.0e-30f) & (s2 < 1.0e30f);
+    const float o1 = l1f(r.o);
+    const float Sb = o1 + scene_p1max;
+    r.en_ray = 6.0f * U * o1;
+    r.eray = 1.0e-13f * Sb * Sb;
+    r.efront = 16.0f * U * (Sb + r.dist);
+    return r;
+}
+// (src/objects.h:42-44) for -dot(normal, feeler.dir) = facing.
+__device__ __forceinline__ float transmission_facing(float facing, float transparency) {
+    const float fres = mix_tenth(1.0f - facing, 0.0f);
+    return (1.0f - fres) * transparency;
+}
+// A sphere the line test has not ruled out.  Returns true when the answer is certain; then
+// `hit` tells which, and for a hit `factor` receives the occluder's transmission factor.
+__device__ __forceinline__ bool classify_sphere(const LRec& l, float t, float r2, float ehit, float transparency,
+                                                const FeelRay& r, bool& hit, float& factor) {
+    const F3 P = f3(__builtin_fmaf(-t, r.d.x, l.x), __builtin_fmaf(-t, r.d.y, l.y), __builtin_fmaf(-t, r.d.z, l.z));
+    const float x = r2 - dotf(P, P);
+    const float tca = t + r.dist;
+    // (32 eray: the reference's rounding, and what a line admitted by the line test with a
+    // large eray - a far origin - adds to the error of x beyond ehit)
+    const float e0 = __builtin_fmaf(32.0f, r.eray, ehit);
+    const bool opaque = transparency == 0.0f;
+    const float khit = opaque ? e0 : __builtin_fmaf(63.0f, ehit, e0);
+    const bool miss = (x < -e0) | (tca < -r.efront);
+    bool sure_hit = (x > khit) & (tca > r.efront);
+    // which root the reference takes (only a transparent occluder's colour depends on it)
+    const float w = __builtin_fmaf(tca, tca, -x);
+    const float band = __builtin_fmaf(r.efront, tca + tca + r.efront, e0);
+    sure_hit = sure_hit & (opaque | (__builtin_fabsf(w) > band));
+    hit = sure_hit;
+    if (sure_hit & !opaque) {
+        const float thc_over_r = __builtin_sqrtf(x) * __builtin_amdgcn_rsqf(r2);
+        factor = transmission_facing((w < 0.0f) ? -thc_over_r : thc_over_r, transparency);
+    } else if (sure_hit) {
+        factor = 0.0f;
+    }
+    return miss | sure_hit;
+}
+// A plane (record as in certain_miss()).  Same return convention.
+__device__ __forceinline__ bool classify_plane(const FRec& g, float transparency, const FeelRay& r, bool& hit, float& factor) {
+    const float U = 6.0e-8f;
+    const F3 n = f3(g.a0, g.a1, g.a2);
+    const float denom = dotf(r.d, n);
+    const float num = g.b0 - dotf(r.o, n);
+    const float en = r.en_ray + g.b1;
+    const float eden = 12.0f * U;
+    const bool nz = __builtin_fabsf(num) > en;
+    const float sgn = num * denom;
+    const bool miss = nz & (__builtin_fabsf(denom) > eden) & (sgn < 0.0f);
+    const bool sure_hit = nz & (__builtin_fabsf(denom) > 1.00001e-6f + eden) & (sgn > 0.0f);
+    hit = sure_hit;
+    if (sure_hit) factor = transmission_facing(-denom, transparency);
+    return miss | sure_hit;
+}
+// The float search through the light's anchor grid: planes (a short list), then the spheres of
+// the lane's own cell, in ascending index.  Returns the first occluder (-1: none) for the lanes
+// that stay certain; `unsure` is set for the others.
+template <typename AT>
+__device__ __forceinline__ int feeler_float_grid(AT& a, GridList gl, const FeelRay& fr, int cur, float& occl, bool& unsure) {
+    int best = 0x7fffffff;
+    unsure = false;
+    cfdata_t pp = (cfdata_t)(const float*)a.planes;
+    for (int k = 0; k < a.n_planes; ++k, pp += 8) {
+        const int idx = __float_as_int(pp[6]);
+        if ((idx != cur) & (idx < best) & !unsure) {
+            bool hit;
+            float factor = 0.0f;
+            const bool sure = classify_plane(load_rec(pp), pp[7], fr, hit, factor);
+            unsure = !sure;
+            if (sure & hit) { best = idx; occl = factor; }
+        }
+    }
+    if (!unsure) {
+        const GridEntry* e = gl.e;
+        for (uint32_t n = gl.n; n != 0u; --n, ++e) {
+            const int idx = e->index;
+            if (idx >= best) break;
+            const LRec l = entry_lrec(e);
+            const float t = __builtin_fmaf(l.z, fr.d.z, __builtin_fmaf(l.y, fr.d.y, l.x * fr.d.x));
+            if ((idx == cur) | (__builtin_fmaf(-t, t, l.thr) > fr.eray)) continue;
+            bool hit;
+            float factor = 0.0f;
+            const bool sure = classify_sphere(l, t, e->r2, e->ehit, e->transparency, fr, hit, factor);
+            if (!sure) { unsure = true; break; }
+            if (hit) { best = idx; occl = factor; break; }
+        }
+    }
+    return (best != 0x7fffffff) ? best : -1;
+}
+
 // The object loops take the scene four records at a time: the float records of a group
 // are fetched up front (scalar loads at constant offsets from one pointer), each slot
 // costs a handful of scalar instructions, and the double record of a primitive is only
 // fetched when some lane's filter cannot rule it out.  `rem` < 4 limits a trailing group.
-constexpr int kGroup = 4;
 struct FGroup {
     FRec r[kGroup];
 };
@@ -977,6 +1121,39 @@ __device__ __forceinline__ int shadow_feeler(AT& a, cdata_t geom, cfdata_t fgeom
     }
     if (!all_lanes(ok)) {
         if (!ok) first = shadow_feeler_general<COUNT, TREE, false>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur, cur_plane, occl, c_sph, c_pln);
+    }
+    return first;
+}
+
+// One shadow feeler from `ip` towards light `li` at `lpos` in a launch that uses the anchor
+// grids: the certified float search first, the double search for the lanes it leaves unsure.
+// Returns the first occluder in container order (-1: none), `occl` its transmission factor;
+// `fd` receives the float direction (what the diffuse term uses, whichever search answered).
+template <bool COUNT, bool TREE, typename AT>
+__device__ __forceinline__ int feeler_by_grid(AT& a, cdata_t geom, cfdata_t fgeom, cfdata_t ltab, int li, V3 ip, V3 lpos,
+                                              int cur, bool cur_plane, float& occl, F3& fd, uint32_t& c_sph, uint32_t& c_pln) {
+    const V3 v = lpos - ip;
+    const FeelRay fr = feel_ray(ip, v, a.scene_p1max);
+    fd = fr.d;
+    RT_MARK("grid_cell");
+    bool ok;
+    const GridList gl = grid_list(a, li, fr.d, ok);
+    ok = ok & (fr.eray <= a.grid_eray_max) & fr.valid;
+    RT_MARK("grid_walk");
+    bool unsure;
+    int first = feeler_float_grid(a, gl, fr, cur, occl, unsure);
+    unsure = unsure | !ok;
+#ifndef RT_PHASE_PROFILE
+    if (COUNT && !unsure) count_feeler_tests(a, first, cur, cur_plane, c_sph, c_pln);
+#endif
+    RT_MARK("feeler_exact_search");
+    if (!all_lanes(!unsure)) {
+        if (unsure) {
+            const V3 fdir = unit(v);  // feeler.dir (src/objects.h:38, src/common.h:27-31)
+            FilterRay ffr = filter_origin(ip, a.scene_p1max);
+            occl = 1.0f;
+            first = shadow_feeler<COUNT, TREE, false, true>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur, cur_plane, occl, c_sph, c_pln);
+        }
     }
     return first;
 }

@@ -277,12 +277,19 @@ __global__ void debug_occluder_kernel(KArgs a, int light, int self, const double
     const cdata_t lights = (cdata_t)(const double*)a.lights;
     const V3 ip = mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
     const LightRec L = load_light(lights, light);
-    const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);
-    FilterRay ffr = filter_origin(ip, a.scene_p1max);
     float occl = 1.0f;
     uint32_t c0 = 0, c1 = 0;
-    const int first = shadow_feeler<false, TREE, false, GRID>(a, geom, (cfdata_t)(const float*)a.fgeom, (cfdata_t)(const float*)a.ltab,
-                                                 light, ffr, ip, fdir, self, false, occl, c0, c1);
+    int first;
+    if (GRID) {
+        F3 fd;
+        first = feeler_by_grid<false, TREE>(a, geom, (cfdata_t)(const float*)a.fgeom, (cfdata_t)(const float*)a.ltab, light, ip,
+                                            mk(L.pos[0], L.pos[1], L.pos[2]), self, false, occl, fd, c0, c1);
+    } else {
+        const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);
+        FilterRay ffr = filter_origin(ip, a.scene_p1max);
+        first = shadow_feeler<false, TREE, false, false>(a, geom, (cfdata_t)(const float*)a.fgeom, (cfdata_t)(const float*)a.ltab,
+                                                         light, ffr, ip, fdir, self, false, occl, c0, c1);
+    }
     first_out[i] = first;
     factor_out[i] = occl;
 }

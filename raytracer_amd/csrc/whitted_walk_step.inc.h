@@ -57,23 +57,32 @@
 
             // ---- Object::Shade, src/objects.h:20-65 ----
             float sr = 0.0f, sg = 0.0f, sb = 0.0f;
-            FilterRay ffr = filter_origin(ip, a.scene_p1max);  // shared by the feelers of this hit
+            FilterRay ffr;  // launches without the anchor grids: shared by the feelers of this hit
+            if (!GRID) ffr = filter_origin(ip, a.scene_p1max);
             for (int li = 0; li < a.n_lights; ++li) {
                 RT_MARK("feeler_dir");
                 RT_ENTER(cnt[4]);
                 const LightRec L = load_light(lights, li);
-                const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);  // feeler.dir
                 float occl = 1.0f;
+                F3 fd;  // feeler.dir in single precision
+                int first;
                 RT_EVENT(++c_feel);
-                RT_MARK("feeler_loop");
-                const int first = shadow_feeler<COUNT, TREE, LATE, GRID>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur,
-                                                             __double2hiint(gr2) < 0, occl, c_fex, c_pln);
+                if (GRID) {
+                    first = feeler_by_grid<COUNT, TREE>(a, geom, fgeom, ltab, li, ip, mk(L.pos[0], L.pos[1], L.pos[2]), cur,
+                                                        __double2hiint(gr2) < 0, occl, fd, c_fex, c_pln);
+                } else {
+                    const V3 fdir = unit(mk(L.pos[0], L.pos[1], L.pos[2]) - ip);  // feeler.dir
+                    RT_MARK("feeler_loop");
+                    first = shadow_feeler<COUNT, TREE, LATE, false>(a, geom, fgeom, ltab, li, ffr, ip, fdir, cur,
+                                                                    __double2hiint(gr2) < 0, occl, c_fex, c_pln);
+                    fd = ffr.d;
+                }
                 RT_EVENT(if (first >= 0) ++c_occ);
                 RT_MARK("feeler_diffuse");
-                // src/objects.h:50-60 (light_dir is the same vector as feeler.dir, whose float
-                // image the filter holds).  The reference divides by length(normal) *
-                // length(light_dir): both are 1 to a few 2^-53, so the quotient is left out.
-                const float dk = __builtin_fabsf(dotf(nf, ffr.d)) * occl;
+                // src/objects.h:50-60 (light_dir is the same vector as feeler.dir).  The reference
+                // divides by length(normal) * length(light_dir): both are 1 to a few 2^-53, so the
+                // quotient is left out.
+                const float dk = __builtin_fabsf(dotf(nf, fd)) * occl;
                 sr = __builtin_fmaxf(__builtin_fmaf(kd.x * L.ci[0], dk, sr), 0.0f);
                 sb = __builtin_fmaxf(__builtin_fmaf(kd.z * L.ci[2], dk, sb), 0.0f);
                 sg = __builtin_fmaxf(__builtin_fmaf(kd.y * L.ci[1], dk, sg), 0.0f);
