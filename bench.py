@@ -38,14 +38,18 @@ is 5 % of the headline step, so bracketing every launch would slow the timed reg
 
 roofline: the path is bound by the vector ALUs, not by MFMA or HBM, so `bound` is "valu" and
 `peak` is the gfx950 FP32 vector peak, 157.3 TFLOP/s.  achieved = algorithmic flops of one
-launch / mean kernel time measured with HIP events around every timed launch, on the stream the
+launch / median kernel time measured with HIP events around timed launches, on the stream the
 kernel runs on.  Algorithmic flops = event counts x a fixed cost table (FLOP_TABLE): the
-reference's arithmetic as written, whatever the kernel does to avoid it (for the scene with the
-sphere tree this is the brute-force count the reference would execute, an equivalent rate).
-`frac_of_fp64_rate` gives the same figure against 78.6 TFLOP/s, the rate at which the chip
-issues the unfused double operations the path computes in.  `traffic` and the executed
-vector-instruction figures come from the PMC profiles committed under profiles/ (null when
-none matches the workload).
+reference's arithmetic as written for the events of the walk the kernel makes (a hit whose
+children are not walked is not credited with their set-up).  A workload whose kernel searches
+the scene through an acceleration structure (sphere tree, anchor grids: from 8 spheres on) never
+executes the reference's brute-force tests, so there `achieved` / `frac` are the rate of the
+vector lane-operations the kernel really executed (PMC profile of the same launch) against the
+unfused rate, 78.6 T/s, and the brute-force count is reported as `equivalent_*`.
+`frac_of_fp64_rate` gives the algorithmic figure against 78.6 TFLOP/s, the rate at which the chip
+issues the unfused double operations the path computes in.  `traffic` and the
+`executed_builder_profile` figures come from the PMC profiles the builder committed under
+profiles/ (measured on the builder's box, not in this run; null when none matches the workload).
 
 cpu_baseline: the single-thread CPU checker (oracle/, a C port of the reference's path)
 timed on this host on whole frames of the same workload, rank 0 at N=1 only.
@@ -81,8 +85,10 @@ FLOP_TABLE = {
     "sphere_tests": 17,      # L, tca, d2, compare (src/objects.h:125-130)
     "plane_tests": 14,       # two dots, a subtraction, a division (src/objects.h:92-96)
     "pixels": 14,            # primary ray: pixel centre + normalisation
-    "hits": 37 + 30 + 16 + 45,  # hit setup, reflection ray, refraction k, combine
-    "refractions": 26,       # refraction ray when k > 0
+    "hits": 37 + 45,         # hit setup (src/main.cc:55-65) and combine (src/main.cc:100-112)
+    "reflections": 9 + 30,   # V / |dot| and the reflection ray, where that child is walked (src/main.cc:70-79)
+    "refraction_tests": 16,  # k, where it is evaluated (src/main.cc:86)
+    "refraction_rays": 26,   # the refraction ray, where that child is walked (src/main.cc:88-93)
     "feelers": 45,           # feeler direction + diffuse term
     "feelers_occluded": 25,  # occluder normal + transmission factor
 }
@@ -102,25 +108,31 @@ EXTRA_WORKLOADS = ("spheres1024_4k_d5", "glass_4k_d8")
 COUNT_FLAGS = abi.RT_FLAG_COUNTERS | abi.RT_FLAG_PRUNE
 LATE_MIN_LIGHTS = 4    # kLateMinLights of the kernel launcher
 TREE_MIN_SPHERES = 40  # kTreeMinSpheres
+GRID_MIN_SPHERES = 8   # kGridMinSpheres
 
 
 def algorithmic_flops(counters, pixels: int) -> float:
-    f = FLOP_TABLE["pixels"] * pixels
-    for k, c in FLOP_TABLE.items():
-        if k != "pixels":
-            f += c * int(counters[k])
-    return float(f)
+    ev = {k: int(counters[k]) for k in abi.COUNTER_FIELDS}
+    ev["pixels"] = pixels
+    # every ray but the primary ones is a reflection or a refraction child that is walked
+    ev["refraction_rays"] = ev["rays"] - pixels - ev["reflections"]
+    return float(sum(c * ev[k] for k, c in FLOP_TABLE.items()))
+
+
+def n_spheres(prims) -> int:
+    return len(prims) - int((prims["type"] == abi.RT_PRIM_PLANE).sum())
 
 
 def kernel_name(prims, lights, depth: int, batched: bool) -> str:
     """The instantiation the launcher picks, spelt as the profiler prints it."""
     b = lambda v: "true" if v else "false"
-    tree = len(prims) - int((prims["type"] == abi.RT_PRIM_PLANE).sum()) >= TREE_MIN_SPHERES
+    tree = n_spheres(prims) >= TREE_MIN_SPHERES
+    grid = n_spheres(prims) >= GRID_MIN_SPHERES
     deep = depth > 5
-    late = (not tree) and len(lights) >= LATE_MIN_LIGHTS
+    late = (not tree) and (not grid) and len(lights) >= LATE_MIN_LIGHTS
     if batched:
-        return f"void rt::whitted_batch_kernel<{b(tree)}, {b(deep)}, {b(late)}>(rt::KBatch, int)"
-    return f"void rt::whitted_kernel<0, false, {b(tree)}, {b(deep)}, {b(late)}>(rt::KArgs)"
+        return f"void rt::whitted_batch_kernel<{b(tree)}, {b(deep)}, {b(late)}, {b(grid)}>(rt::KBatch, int)"
+    return f"void rt::whitted_kernel<0, false, {b(tree)}, {b(deep)}, {b(late)}, {b(grid)}>(rt::KArgs, rt::SkyTable)"
 
 
 def cpu_baseline(prims, lights, base, budget_s: float = 12.0):
@@ -197,35 +209,52 @@ def _profile_record(workload: str) -> dict:
 
 def roofline(prims, lights, depth, batched, flops, kernel_ms_list, fb_bytes, workload, with_profile=True):
     ms = np.asarray(kernel_ms_list, dtype=np.float64)
-    mean = float(ms.mean()) if ms.size else float("nan")
-    achieved = flops / (mean * 1e-3) / 1e12
+    med = float(np.median(ms)) if ms.size else float("nan")  # (a stray slow launch does not move it)
+    algorithmic = flops / (med * 1e-3) / 1e12
     prof = _profile_record(workload) if with_profile else {}
+    accelerated = n_spheres(prims) >= GRID_MIN_SPHERES  # sphere tree and / or anchor grids
     out = {
         "bound": "valu",
-        "achieved": achieved,
+        "achieved": algorithmic,
         "peak": PEAK_FP32_VALU_TFLOPS,
         "unit": "TFLOP/s",
-        "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-        "frac_of_fp64_rate": achieved / RATE_FP64_VALU_TFLOPS,
+        "frac": algorithmic / PEAK_FP32_VALU_TFLOPS,
+        "frac_of_fp64_rate": algorithmic / RATE_FP64_VALU_TFLOPS,
         "traffic": prof.get("hbm_bytes_per_launch"),
+        "traffic_from": "builder profile: " + prof["source"] if prof.get("source") else None,
         "kernel": kernel_name(prims, lights, depth, batched),
-        "kernel_ms": mean,
+        "kernel_ms": med,
+        "kernel_ms_mean": float(ms.mean()) if ms.size else None,
         "kernel_ms_min": float(ms.min()) if ms.size else None,
-        "kernel_ms_median": float(np.median(ms)) if ms.size else None,
         "kernel_ms_max": float(ms.max()) if ms.size else None,
         "algorithmic_flops_per_launch": flops,
-        "framebuffer_write_GBps": fb_bytes / (mean * 1e-3) / 1e9,
+        "framebuffer_write_GBps": fb_bytes / (med * 1e-3) / 1e9,
     }
+    executed = None
     if prof.get("valu_insts_per_launch"):
-        # what the kernel really executed (PMC pass of the same launch, profiles/)
+        # what the kernel really executed (PMC pass of the same launch on the builder's box)
         lane_ops = prof["valu_insts_per_launch"] * 64.0 * prof.get("lane_utilisation", 1.0)
-        out["executed"] = {
+        executed = {
             "valu_wave_insts_per_launch": prof["valu_insts_per_launch"],
             "lane_utilisation": prof.get("lane_utilisation"),
             "valu_busy": prof.get("valu_busy"),
-            "lane_ops_per_s": lane_ops / (mean * 1e-3),
+            "lane_ops_per_s": lane_ops / (med * 1e-3),
             "source": prof.get("source"),
         }
+        out["executed_builder_profile"] = executed
+    if accelerated:
+        # the brute-force tests the event counts stand for are never executed: report them as an
+        # equivalent rate and rate the kernel on what it executes
+        out["equivalent_TFLOPs"] = algorithmic
+        out["equivalent_frac"] = algorithmic / PEAK_FP32_VALU_TFLOPS
+        out["equivalent_flops_per_launch"] = flops
+        rate = executed["lane_ops_per_s"] / 1e12 if executed else None
+        out["achieved"] = rate
+        out["peak"] = RATE_FP64_VALU_TFLOPS
+        out["unit"] = "T lane-ops/s (executed vector lane-operations, builder profile, against the unfused rate)"
+        out["frac"] = rate / RATE_FP64_VALU_TFLOPS if rate is not None else None
+        out["frac_of_fp64_rate"] = out["frac"]
+        del out["algorithmic_flops_per_launch"]
     return out
 
 
@@ -283,7 +312,7 @@ def run_mode(mode, ctx):
     my_rows = abi.strip_rows(my)
 
     # untimed counter launch: rays and event counts of this rank's share of one frame
-    d_cnt = torch.zeros(8, dtype=torch.int64, device=device)
+    d_cnt = torch.zeros(len(abi.COUNTER_FIELDS), dtype=torch.int64, device=device)
     scratch = torch.zeros((max(my_rows, 1), width, 3), dtype=torch.uint8, device=device)
     pc = my.copy()
     pc["flags"] = COUNT_FLAGS
@@ -462,7 +491,7 @@ def end_to_end(tracer, prims, lights, base, cpu_ms_per_frame):
     with tempfile.TemporaryDirectory() as tmp:
         if os.path.exists(exe):
             t0 = time.perf_counter()
-            r = subprocess.run([exe, "--width", str(w), "--height", str(h), "--depth", str(d), "--out",
+            r = subprocess.run([exe, "--width", str(w), "--height", str(h), "--depth", str(d), "--frames", "1", "--out",
                                 os.path.join(tmp, "gpu.bmp")], capture_output=True, text=True, timeout=300)
             wall = time.perf_counter() - t0
             if r.returncode == 0:
@@ -472,6 +501,17 @@ def end_to_end(tracer, prims, lights, base, cpu_ms_per_frame):
                         out["main_equivalent_s_gpu"] = float(line.split()[1])
                     if line.startswith("Tracer:"):
                         out["tracer_call_s_gpu"] = float(line.split()[1])
+            # a sequence of frames: what the first Tracer() call of a process is made of, and what
+            # every later call costs (src/main.cc:226-231 called once per frame)
+            r = subprocess.run([exe, "--width", str(w), "--height", str(h), "--depth", str(d), "--frames", "3", "--out",
+                                os.path.join(tmp, "gpu.bmp")], capture_output=True, text=True, timeout=300)
+            if r.returncode == 0:
+                for line in r.stdout.splitlines():
+                    if line.startswith("TracerFirst:"):
+                        out["tracer_first_call_s"] = float(line.split()[1])
+                        out["tracer_first_call_parts"] = line.split("(", 1)[1].rstrip(")")
+                    if line.startswith("TracerNext:"):
+                        out["tracer_next_call_s"] = float(line.split()[1])
         if cpu_ms_per_frame:
             from tests import oracle_lib
 
@@ -492,7 +532,7 @@ def extra_workload(name, torch, device, stream, local_rank, steps=3, warmup=1, c
     tracer = DeviceTracer(local_rank)
     tracer.upload_scene(prims, lights)
     out = torch.zeros((height, width, 3), dtype=torch.uint8, device=device)
-    d_cnt = torch.zeros(8, dtype=torch.int64, device=device)
+    d_cnt = torch.zeros(len(abi.COUNTER_FIELDS), dtype=torch.int64, device=device)
     pc = base.copy()
     pc["flags"] = COUNT_FLAGS
     tracer.render_device(pc, stream.cuda_stream, out.data_ptr(), d_counters=d_cnt.data_ptr())
@@ -587,6 +627,14 @@ def main():
         modes = ["batch", "gather", "strips"]  # `value` comes from the first one
     else:
         modes = [args.mode]
+    # what every rank runs on, as the process group sees it (rank 0 prints it)
+    me = f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"
+    if world > 1:
+        names = [None] * world
+        dist.all_gather_object(names, me)
+        ctx["rank_devices"] = names
+    else:
+        ctx["rank_devices"] = [me]
     results = [run_mode(m, ctx) for m in modes]
 
     if rank == 0:
@@ -602,7 +650,7 @@ def main():
             "higher_is_better": True,
             "scaling": head["scaling"],
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64 decisions / f32 colour",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {width}x{height}, max_depth {depth}, {len(prims)} objects, "
@@ -619,6 +667,8 @@ def main():
                                  head["fb_bytes"], args.workload, with_profile=(world == 1)),
         }
         if world > 1:
+            line["config"]["rccl_ranks"] = dist.get_world_size()
+            line["config"]["rank_devices"] = ctx["rank_devices"]
             line["modes"] = {
                 r["mode"]: {
                     "value": r["value"], "unit": "Mrays/s", "ms_per_step": r["ms_per_step"], "scaling": r["scaling"],

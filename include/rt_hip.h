@@ -140,6 +140,11 @@ typedef struct rt_counters {
     uint64_t feelers;         /* (hit, light) pairs shaded                               */
     uint64_t feelers_occluded;/* feelers that met an occluder                            */
     uint64_t refractions;     /* refraction children spawned (k > 0, src/main.cc:87)     */
+    uint64_t reflections;     /* reflection children traced: TraceRay calls for them that
+                                 pass the depth stop (src/main.cc:80, 31-34)             */
+    uint64_t refraction_tests;/* hits at which k is evaluated (src/main.cc:86): all of
+                                 them, or under RT_FLAG_PRUNE those on an object whose
+                                 transparency is not zero                                */
 } rt_counters;
 
 typedef struct rt_ctx rt_ctx;

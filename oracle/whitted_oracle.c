@@ -200,11 +200,13 @@ static void trace_ray(octx* c, v3 o, v3 d, int depth, uint32_t node, double out[
     if (!(c->prune && (float)obj->reflectivity == 0.0f)) { /* src/main.cc:74-81 */
         v3 rd = v3_unit(v3_add(vt, v3_scale(n, 2.0)));
         v3 ro = v3_add(ip, v3_scale(n, 1e-4));
+        if (c->cnt && depth + 1 < c->max_depth) c->cnt->reflections++;
         trace_ray(c, ro, v3_unit(rd), depth + 1, 2 * node, refl);
     }
     double trans[3] = {0.0, 0.0, 0.0};
     {                                                    /* src/main.cc:84-97 */
         double k = (ri * ri) * v3_len2(vt) - v3_len2(v3_add(vt, n));
+        if (c->cnt && !(c->prune && (float)obj->transparency == 0.0f)) c->cnt->refraction_tests++;
         if (k > 0 && !(c->prune && (float)obj->transparency == 0.0f)) {
             v3 td = v3_sub(v3_scale(v3_add(n, vt), 1.0 / sqrt(k)), n);
             td = v3_unit(td);

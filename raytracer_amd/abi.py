@@ -64,13 +64,15 @@ COUNTER_FIELDS = (
     "feelers",
     "feelers_occluded",
     "refractions",
+    "reflections",
+    "refraction_tests",
 )
 COUNTERS_DTYPE = np.dtype([(f, "<u8") for f in COUNTER_FIELDS])
 
 assert PRIM_DTYPE.itemsize == 112
 assert LIGHT_DTYPE.itemsize == 56
 assert PARAMS_DTYPE.itemsize == 64
-assert COUNTERS_DTYPE.itemsize == 64
+assert COUNTERS_DTYPE.itemsize == 80
 
 
 def mask_words(max_depth: int) -> int:

@@ -64,7 +64,6 @@ struct rt_ctx {
     std::map<void*, void*> workspaces;
     std::map<void*, void*> queues;   // streams that only ever needed the tile queue (256 bytes)
     size_t workspace_bytes = 0;
-    void* static_ws = nullptr;  // the library's built-in workspace on this device
     // host copy of the scene and the screen bounds worked out from it (sky_table.h), kept per
     // partition the context has rendered lately
     std::vector<rt_prim> host_prims;
@@ -300,8 +299,6 @@ int rt_create(int32_t device_id, rt_ctx** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copies_done, hipEventDisableTiming);
-    // the built-in workspace of rt_render_device_static: its address on THIS device
-    if (e == hipSuccess) e = rt::static_workspace(device_id, &ctx->static_ws);
     if (e != hipSuccess) {
         rt_destroy(ctx);
         return hip_fail(nullptr, e, "rt_create: device set-up");
@@ -650,7 +647,6 @@ int rt_render_device_static(rt_ctx* ctx, const rt_params* p, void* stream, uint8
                             uint32_t* d_hit_mask, uint32_t* d_spawn_mask, rt_counters* d_counters) {
     if (!ctx) return RT_ERR_ARG;
     if (!d_bgr) return fail(ctx, RT_ERR_ARG, "rt_render_device_static: d_bgr is null");
-    if (!ctx->static_ws) return fail(ctx, RT_ERR_STATE, "rt_render_device_static: built-in workspace not available");
     // the built-in workspace holds the stacks of kDeepMaxBlocks blocks at RT_MAX_DEPTH;
     // a depth it has no room for is refused here (and by the parameter check for every
     // entry point while RT_MAX_DEPTH is the library's limit)
@@ -659,8 +655,11 @@ int rt_render_device_static(rt_ctx* ctx, const rt_params* p, void* stream, uint8
                                      "workspace holds (limit: max_depth 8)");
     DeviceGuard guard(ctx->device);
     RT_HIP_TRY(ctx, guard.status);
-    return enqueue_render(ctx, p, static_cast<hipStream_t>(stream), ctx->static_ws, d_bgr, d_hit_id, d_hit_mask,
-                          d_spawn_mask, d_counters);
+    // the built-in workspace's address on this device (looked up at the first such call)
+    void* ws = nullptr;
+    RT_HIP_TRY(ctx, rt::static_workspace(ctx->device, &ws));
+    return enqueue_render(ctx, p, static_cast<hipStream_t>(stream), ws, d_bgr, d_hit_id, d_hit_mask, d_spawn_mask,
+                          d_counters);
 }
 
 int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t n, void* stream,

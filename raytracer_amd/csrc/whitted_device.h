@@ -79,6 +79,8 @@ static_assert(sizeof(GridCell) == 8 && sizeof(GridEntry) == 32, "record size");
 
 // Per-lane stack entry: origin xyz, direction xyz, and one field that holds the path weight
 // (float) and the node number.
+constexpr int kCounters = 10;  // fields of rt_counters
+static_assert(sizeof(rt_counters) == kCounters * sizeof(uint64_t), "rt_counters");
 constexpr int kStackFields = 7;
 constexpr int kWavesPerBlock = 4;
 constexpr int kTile = 8;  // a wave renders an 8x8 pixel tile
@@ -103,7 +105,7 @@ struct KArgs {
     int32_t* hit_id;
     uint32_t* hit_mask;
     uint32_t* spawn_mask;
-    unsigned long long* counters;  // 8 x u64, same order as rt_counters
+    unsigned long long* counters;  // kCounters x u64, same order as rt_counters
     int32_t n_prims, n_lights;
     int32_t n_nodes, n_planes;
     int32_t ltab_stride;       // records per light: n_prims rounded up to a multiple of 4
@@ -207,8 +209,8 @@ static_assert(sizeof(KBatch) <= 3072, "kernel argument segment");
 // deep_blocks: grid of a deep-stack launch (deep_grid_blocks), ignored otherwise.
 hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, bool grid, int deep_blocks, hipStream_t stream);
 
-// The library's built-in workspace (a file-scope device array of kWorkspaceMaxBytes): its
-// address on the CURRENT device, looked up once per device.
+// The library's built-in workspace (static_workspace.hip: a file-scope device array of
+// kWorkspaceMaxBytes): its address on `device`, which must be current; looked up once per device.
 hipError_t static_workspace(int device, void** ptr);
 
 // Enqueue the render of one strip on `stream`.  emit = write hit_id/masks (pointers in

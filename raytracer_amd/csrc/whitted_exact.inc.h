@@ -1255,12 +1255,12 @@ __device__ __forceinline__ void take_pixels(TileQueue& f, CArgs*& ap, bool& have
 #define RT_WALK_COUNTERS                                                                                      \
     uint32_t dummy = 0;                                                                                       \
     uint32_t &c_rays = dummy, &c_phits = dummy, &c_hits = dummy, &c_sph = cnt[1], &c_pln = dummy, &c_feel = dummy, \
-             &c_occ = dummy, &c_refr = dummy, &c_fex = cnt[5];
+             &c_occ = dummy, &c_refr = dummy, &c_refl = dummy, &c_ktest = dummy, &c_fex = cnt[5];
 #define RT_EVENT(x) ((void)0)
 #else
 #define RT_WALK_COUNTERS                                                                                      \
     uint32_t &c_rays = cnt[0], &c_phits = cnt[1], &c_hits = cnt[2], &c_sph = cnt[3], &c_pln = cnt[4],       \
-             &c_feel = cnt[5], &c_occ = cnt[6], &c_refr = cnt[7];                                            \
+             &c_feel = cnt[5], &c_occ = cnt[6], &c_refr = cnt[7], &c_refl = cnt[8], &c_ktest = cnt[9];       \
     uint32_t& c_fex = c_sph;
 #define RT_EVENT(x) do { if (COUNT) { x; } } while (0)
 #endif
@@ -1309,7 +1309,7 @@ __device__ __forceinline__ void store_pixel(AT& a, int x, int k, float cr, float
 // lanes without a pixel.
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, bool GRID, typename AT>
 __device__ __forceinline__ void trace_tile(AT& a, const int x, const int k, bool have, double* stk, double* gstk,
-                                           const int lane, uint32_t (&cnt)[8]) {
+                                           const int lane, uint32_t (&cnt)[kCounters]) {
     const cdata_t geom = (cdata_t)(const double*)a.geom;
     const cdata_t lights = (cdata_t)(const double*)a.lights;
     const cfdata_t fgeom = (cfdata_t)(const float*)a.fgeom;
@@ -1351,7 +1351,7 @@ __device__ __forceinline__ void trace_tile(AT& a, const int x, const int k, bool
 // One wave of a launch with a fixed grid: pixels from the tile queue until it is empty.
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, bool GRID>
 __device__ __forceinline__ void trace_queue(TileQueue& feed, double* stk, double* gstk, const int lane,
-                                            uint32_t (&cnt)[8]) {
+                                            uint32_t (&cnt)[kCounters]) {
     CArgs* ap = feed.renders + feed.cur;
     int x = 0, k = 0;
     bool have = false;

@@ -24,39 +24,16 @@ constexpr int kLateMinLights = 4;
 constexpr int image_waves(bool grid) { return grid ? RT_GRID_WAVES : RT_IMAGE_WAVES; }
 
 template <bool COUNT, typename AT>
-__device__ __forceinline__ void flush_counters(AT& a, const uint32_t (&cnt)[8], int lane) {
+__device__ __forceinline__ void flush_counters(AT& a, const uint32_t (&cnt)[kCounters], int lane) {
     if (COUNT) {
-        unsigned long long s[8];
+        unsigned long long s[kCounters];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s[i] = wave_sum(cnt[i]);
+        for (int i = 0; i < kCounters; ++i) s[i] = wave_sum(cnt[i]);
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) atomicAdd(&a.counters[i], s[i]);
+            for (int i = 0; i < kCounters; ++i) atomicAdd(&a.counters[i], s[i]);
         }
     }
-}
-
-// The library's own workspace for deep-stack launches made through the entry point that
-// must not allocate (rt_render_device_static): tile queue + one stack region per wave of the
-// largest deep grid.  Each GPU the library runs on holds its own copy until the process
-// ends.  Host code never uses the array's name as an address: static_workspace() asks the
-// runtime for the device address, once per device.
-static __device__ __align__(256) unsigned char scratch[kWorkspaceMaxBytes];
-
-constexpr int kMaxDevices = 64;
-static void* g_scratch_ptr[kMaxDevices];
-
-hipError_t static_workspace(int device, void** ptr) {
-    *ptr = nullptr;
-    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
-    if (!g_scratch_ptr[device]) {
-        void* p = nullptr;
-        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));  // of the current device
-        if (e != hipSuccess) return e;
-        g_scratch_ptr[device] = p;
-    }
-    *ptr = g_scratch_ptr[device];
-    return hipSuccess;
 }
 
 // Region `w` (a wave of the launch) of the global stack workspace, lane-major like the LDS part.
@@ -75,7 +52,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* stk = lds_stack + (size_t)wave * (DEEP ? stack_lds_entries(a.max_depth) : tile_stack_lds_entries(a.max_depth)) * kStackFields * 64 + lane;
-    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t cnt[kCounters] = {0};
     if (DEEP || TREE) {
         double* gstk = DEEP ? wave_gstack(a, (size_t)blockIdx.x * kWavesPerBlock + wave) : nullptr;
         TileQueue feed;
@@ -132,7 +109,7 @@ void whitted_batch_kernel(KBatch, int n) {
     const RT_CONST KBatch& b = *(const RT_CONST KBatch*)__builtin_amdgcn_kernarg_segment_ptr();  // the first argument
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t cnt[kCounters] = {0};
     if (DEEP || TREE) {
         // every render's stack entries sit at the offsets of the deepest render of the launch
         int depth = 0;

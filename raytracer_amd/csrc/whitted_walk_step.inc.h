@@ -128,7 +128,7 @@
             const float wr = w * kr, wt = w * kt;
             const bool go_t = want_t && kk > 0;
             const bool go_r = want_r;
-            RT_EVENT(if (go_t) ++c_refr);
+            RT_EVENT(if (go_t) ++c_refr; if (want_t) ++c_ktest; if (go_r && level + 1 < a.max_depth) ++c_refl);
 
             if (level + 1 >= a.max_depth) {
                 RT_MARK("children_last");

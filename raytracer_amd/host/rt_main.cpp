@@ -51,12 +51,20 @@ int main(int argc, char** argv) {
     else { std::cerr << "unknown scene " << scene << "\n"; return 2; }
     if (orbit_deg != 0.0) OrbitScene(objs, lights, orbit_deg * 3.141592653589793 / 180.0);
 
+    const auto setup_s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
     const auto tr0 = std::chrono::high_resolution_clock::now();
+    TracerTimings first, next;
+    double first_s = 0.0, next_s = 0.0;
     try {
+        opt.timings = &first;
         Tracer(bgr, *screen, objs, lights, opt);
+        first_s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - tr0).count();
+        opt.timings = &next;
         for (int f = 1; f < frames; ++f) {  // more frames of the same scene: what a sequence pays per frame
             screen->DrawScreen();
+            const auto tn = std::chrono::high_resolution_clock::now();
             Tracer(bgr, *screen, objs, lights, opt);
+            next_s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - tn).count();
         }
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << "\n";
@@ -66,6 +74,12 @@ int main(int argc, char** argv) {
     screen->DrawScreen();
 
     const auto t1 = std::chrono::high_resolution_clock::now();
+    std::cout << "Setup: " << setup_s << " Seconds (screen buffers, scene construction)\n";
+    std::cout << "TracerFirst: " << first_s << " Seconds (rt_create " << first.create_s << ", rt_upload_scene "
+              << first.upload_s << ", rt_render " << first.render_s << ")\n";
+    if (frames > 1)
+        std::cout << "TracerNext: " << next_s << " Seconds (rt_render " << next.render_s << "; the last of " << frames - 1
+                  << " further call(s))\n";
     std::cout << "Tracer: " << std::chrono::duration<double, std::milli>(tr1 - tr0).count() / 1000.0 << " Seconds ("
               << frames << " call(s), first one with device set-up)\n";
     std::cout << "Time: " << std::chrono::duration<double, std::milli>(t1 - t0).count() / 1000.0 << " Seconds\n";

@@ -2,6 +2,7 @@
 // call that hands the flattened scene to the device library.
 #include "scene_model.hpp"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -238,22 +239,29 @@ void Tracer(const Color& bgr, Screen& scr, const std::vector<std::unique_ptr<Obj
     lts.reserve(lights.size());
     for (const auto& l : lights) lts.push_back(l->Flatten());
 
+    using clock = std::chrono::steady_clock;
+    const auto since = [](clock::time_point t) { return std::chrono::duration<double>(clock::now() - t).count(); };
+    TracerTimings tm;
     DeviceSlot& slot = device_slots()[opt.device];
     if (!slot.ctx) {
+        const auto t = clock::now();
         if (rt_create(opt.device, &slot.ctx) != RT_OK) {
             slot.ctx = nullptr;
             throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
         }
+        tm.create_s = since(t);
     }
     rt_ctx* ctx = slot.ctx;
     auto fail = [&](const char* what) { throw std::runtime_error(std::string(what) + ": " + rt_last_error(ctx)); };
     if (!same_bytes(prims, slot.prims) || !same_bytes(lts, slot.lights)) {
         slot.prims.clear();
+        const auto t = clock::now();
         if (rt_upload_scene(ctx, prims.data(), static_cast<int32_t>(prims.size()), lts.data(),
                             static_cast<int32_t>(lts.size())) != RT_OK)
             fail("rt_upload_scene");
         slot.prims = prims;
         slot.lights = lts;
+        tm.upload_s = since(t);
     }
 
     rt_params p{};
@@ -269,11 +277,14 @@ void Tracer(const Color& bgr, Screen& scr, const std::vector<std::unique_ptr<Obj
 
     // StorePixel(x, y, 1, colour) for every pixel: when that replaces the whole back buffer
     // the device's frame is copied straight into it
+    const auto t = clock::now();
     if (uint8_t* dst = scr.BeginFrameStore(1)) {
         if (rt_render(ctx, &p, dst, nullptr, nullptr, nullptr, nullptr) != RT_OK) fail("rt_render");
-        return;
+    } else {
+        slot.staging.resize(static_cast<std::size_t>(p.width) * p.height * 3);
+        if (rt_render(ctx, &p, slot.staging.data(), nullptr, nullptr, nullptr, nullptr) != RT_OK) fail("rt_render");
+        scr.StoreRows(0, scr.Height(), 1, slot.staging.data());
     }
-    slot.staging.resize(static_cast<std::size_t>(p.width) * p.height * 3);
-    if (rt_render(ctx, &p, slot.staging.data(), nullptr, nullptr, nullptr, nullptr) != RT_OK) fail("rt_render");
-    scr.StoreRows(0, scr.Height(), 1, slot.staging.data());
+    tm.render_s = since(t);
+    if (opt.timings) *opt.timings = tm;
 }

@@ -218,10 +218,19 @@ private:
     std::string output_path_;
 };
 
+// Where a Tracer() call spent its time (seconds); the first call on a device also creates the
+// device context, a call with a new scene uploads it.
+struct TracerTimings {
+    double create_s = 0.0;   // rt_create (0 when the context existed)
+    double upload_s = 0.0;   // rt_upload_scene (0 when the scene was resident)
+    double render_s = 0.0;   // rt_render: trace + copy into the Screen
+};
+
 struct TracerOptions {
     int max_depth = 4;    // the reference's MAX_DEPTH (src/main.cc:17)
     double fov_deg = 60;  // src/main.cc:126
     int device = 0;
+    TracerTimings* timings = nullptr;  // filled when given
 };
 
 // Drop-in for the reference's Tracer() (src/main.cc:115-120): same arguments, same

@@ -39,7 +39,7 @@ def test_struct_layout_matches_header(tmp_path):
         " offsetof(rt_prim,reflectivity), offsetof(rt_prim,ambient_intensity));\n"
         'printf("%zu %zu %zu %zu\\n", offsetof(rt_params,max_depth), offsetof(rt_params,flags),'
         " offsetof(rt_params,fov_deg), offsetof(rt_params,bgr));\n"
-        'printf("%zu %zu\\n", offsetof(rt_counters,rays), offsetof(rt_counters,refractions));\n'
+        'printf("%zu %zu %zu\\n", offsetof(rt_counters,rays), offsetof(rt_counters,refractions), offsetof(rt_counters,refraction_tests));\n'
         "return 0;}\n"
     )
     exe = tmp_path / "layout"
@@ -52,7 +52,7 @@ def test_struct_layout_matches_header(tmp_path):
         P.fields["p"][1], P.fields["q"][1], P.fields["kd"][1], P.fields["reflectivity"][1],
         P.fields["ambient_intensity"][1],
         R.fields["max_depth"][1], R.fields["flags"][1], R.fields["fov_deg"][1], R.fields["bgr"][1],
-        C.fields["rays"][1], C.fields["refractions"][1],
+        C.fields["rays"][1], C.fields["refractions"][1], C.fields["refraction_tests"][1],
     ]
     assert got == want
 

@@ -69,7 +69,7 @@ def test_render_device_on_torch_stream(tracer):
     hid = torch.zeros((120, 200), dtype=torch.int32, device=dev)
     hm = torch.zeros((120, 200, words), dtype=torch.int32, device=dev)
     sm = torch.zeros((120, 200, words), dtype=torch.int32, device=dev)
-    cnt = torch.zeros(8, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(len(abi.COUNTER_FIELDS), dtype=torch.int64, device=dev)
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         tracer.render_device(p, side.cuda_stream, bgr.data_ptr(), hid.data_ptr(), hm.data_ptr(), sm.data_ptr(),
@@ -255,6 +255,45 @@ def test_strip_exchange_over_rccl_single_rank(tracer):
 
         g = strips.StripGatherer(base, render_strip, dev)
         assert np.array_equal(g.frame(g.submit()).cpu().numpy(), want)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_step_functions_under_rccl_single_rank(tracer):
+    """bench.py's own per-mode step functions (batch, gather, strips: what `bench.py --gpus N`
+    times on every rank) run inside an RCCL process group of one rank: every mode completes,
+    counts the rays of the frames it rendered and reports a kernel time."""
+    import argparse
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    import bench
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        builder, width, height, depth = bench.WORKLOADS["default_640_d4"]
+        prims, lights = builder()
+        tracer.upload_scene(prims, lights)
+        base = abi.make_params(width, height, depth)
+        args = argparse.Namespace(steps=3, warmup=1, event_every=1, dump=None)
+        ctx = dict(torch=torch, dist=dist, world=dist.get_world_size(), rank=dist.get_rank(), local_rank=0, device=dev,
+                   stream=torch.cuda.current_stream(), tracer=tracer, base=base, args=args, prims=prims, lights=lights)
+        for mode in ("batch", "gather", "strips"):
+            r = bench.run_mode(mode, ctx)
+            assert r["mode"] == mode and r["elapsed"] > 0 and len(r["kernel_ms"]) == 3
+            assert r["rays_total"] >= 3 * width * height          # at least the primary rays of three frames
+            assert r["flops_per_launch"] > 14 * width * height
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)                                        # the group itself works
+        assert float(t.sum().item()) == 4.0
     finally:
         dist.destroy_process_group()
 

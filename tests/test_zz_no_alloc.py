@@ -17,7 +17,7 @@ def _render(tracer, static, p, stream, torch):
     hid = torch.full((h, w), -9, dtype=torch.int32, device=dev)
     hm = torch.zeros((h, w, words), dtype=torch.int32, device=dev)
     sm = torch.zeros((h, w, words), dtype=torch.int32, device=dev)
-    cnt = torch.zeros(8, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(len(abi.COUNTER_FIELDS), dtype=torch.int64, device=dev)
     q = p.copy()
     q["flags"] = int(q["flags"]) | abi.RT_FLAG_COUNTERS
     fn = tracer.render_device_static if static else tracer.render_device

@@ -32,7 +32,7 @@ waves = ((w + 7) // 8) * ((h + 7) // 8)
 n = len(prims)
 slots_static = 4 + 3          # the loop body (a group of four) and the remainder (up to three)
 slots_run = n                 # per pass over the scene (container-order loop)
-it, near_ex, miss, hit, feel, feel_ex, child, lane_it = c
+it, near_ex, miss, hit, feel, feel_ex, child, lane_it = c[:8]
 entries = {
     "prologue": waves, "epilogue": waves,
     "iter": it, "iter_tail": it, "pop": it,
