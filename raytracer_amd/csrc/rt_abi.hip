@@ -62,7 +62,10 @@ struct rt_ctx {
     // overlap.  Its size depends on the device only (workspace_bytes), never on the frame;
     // rt_trim() frees them all.
     std::map<void*, void*> workspaces;
-    std::map<void*, void*> queues;   // streams that only ever needed the tile queue (256 bytes)
+    std::map<void*, void*> queues;   // streams that only ever needed the tile queue (256 bytes): slots
+                                     // of `queue_pool` (allocated by rt_create), own allocations beyond
+    void* queue_pool = nullptr;
+    int queue_pool_used = 0;
     size_t workspace_bytes = 0;
     // host copy of the scene and the screen bounds worked out from it (sky_table.h), kept per
     // partition the context has rendered lately
@@ -137,6 +140,11 @@ int check_params(const rt_params* p) {
     return RT_OK;
 }
 
+// Tile queues handed out without an allocation: the first kQueuePoolSlots streams a context
+// makes a queue-only launch on (sphere-tree scenes at max_depth <= 5) take a slot of a pool
+// that rt_create allocated, so such renders can be enqueued where hipMalloc is not allowed.
+constexpr int kQueuePoolSlots = 64;
+
 // The workspace of `stream` for launches with a fixed grid: tile queue + (deep: the stack
 // regions).  Allocated at the first such launch on that stream; a launch that only needs the
 // queue takes the header of the full workspace when the stream has one, else 256 bytes.
@@ -149,27 +157,34 @@ int stream_workspace(rt_ctx* ctx, void* stream, bool deep, void** out) {
     if (deep) {
         void* w = nullptr;
         RT_HIP_TRY(ctx, hipMalloc(&w, ctx->workspace_bytes));
+        RT_HIP_TRY(ctx, hipMemsetAsync(w, 0, rt::kWorkspaceHeader, static_cast<hipStream_t>(stream)));
         ctx->workspaces[stream] = w;
         *out = w;
         return RT_OK;
     }
     void*& q = ctx->queues[stream];
-    if (!q) RT_HIP_TRY(ctx, hipMalloc(&q, rt::kWorkspaceHeader));
+    if (!q) {
+        if (ctx->queue_pool && ctx->queue_pool_used < kQueuePoolSlots)
+            q = static_cast<char*>(ctx->queue_pool) + rt::kWorkspaceHeader * ctx->queue_pool_used++;
+        else {
+            RT_HIP_TRY(ctx, hipMalloc(&q, rt::kWorkspaceHeader));
+            RT_HIP_TRY(ctx, hipMemsetAsync(q, 0, rt::kWorkspaceHeader, static_cast<hipStream_t>(stream)));
+        }
+    }
     *out = q;
     return RT_OK;
 }
 
-// Point the arguments of a deep-stack launch at workspace `ws` and clear its tile queue on
-// `stream`; returns the grid size of the launch (0 when the depth needs no workspace).
-int attach_workspace(rt_ctx* ctx, rt::KArgs* args, int n, long long tiles, int max_depth, void* ws, hipStream_t stream,
-                     int* deep_blocks) {
+// Point the arguments of a launch with a fixed grid at workspace `ws` and work out the grid
+// size.  The tile queue at the head of the workspace is zero whenever no launch is using
+// it: zeroed when the workspace is made, and put back to zero by the last wave of every launch.
+int attach_workspace(rt_ctx* ctx, rt::KArgs* args, int n, long long tiles, int max_depth, void* ws, int* deep_blocks) {
     const bool deep = rt::stack_global_entries(max_depth) > 0;
     *deep_blocks = rt::deep_grid_blocks(ctx->n_cus, tiles, deep);
     for (int i = 0; i < n; ++i) {
         args[i].tile_queue = static_cast<unsigned int*>(ws);
         args[i].gstack = deep ? reinterpret_cast<double*>(static_cast<char*>(ws) + rt::kWorkspaceHeader) : nullptr;
     }
-    RT_HIP_TRY(ctx, hipMemsetAsync(ws, 0, rt::kWorkspaceHeader, stream));
     return RT_OK;
 }
 
@@ -299,6 +314,8 @@ int rt_create(int32_t device_id, rt_ctx** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copies_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(&ctx->queue_pool, rt::kWorkspaceHeader * kQueuePoolSlots);
+    if (e == hipSuccess) e = hipMemset(ctx->queue_pool, 0, rt::kWorkspaceHeader * kQueuePoolSlots);
     if (e != hipSuccess) {
         rt_destroy(ctx);
         return hip_fail(nullptr, e, "rt_create: device set-up");
@@ -311,9 +328,14 @@ static void free_workspaces(rt_ctx* ctx) {
     for (auto& kv : ctx->workspaces)
         if (kv.second) (void)hipFree(kv.second);
     ctx->workspaces.clear();
-    for (auto& kv : ctx->queues)
-        if (kv.second) (void)hipFree(kv.second);
+    const char* pool = static_cast<const char*>(ctx->queue_pool);
+    for (auto& kv : ctx->queues) {
+        const char* q = static_cast<const char*>(kv.second);
+        const bool pooled = pool && q >= pool && q < pool + rt::kWorkspaceHeader * kQueuePoolSlots;
+        if (q && !pooled) (void)hipFree(kv.second);
+    }
     ctx->queues.clear();
+    ctx->queue_pool_used = 0;
 }
 
 void rt_destroy(rt_ctx* ctx) {
@@ -335,6 +357,7 @@ void rt_destroy(rt_ctx* ctx) {
         if (ctx->d_grid_cells) (void)hipFree(ctx->d_grid_cells);
         if (ctx->d_grid_entries) (void)hipFree(ctx->d_grid_entries);
         free_workspaces(ctx);
+        if (ctx->queue_pool) (void)hipFree(ctx->queue_pool);
         for (hipEvent_t ev : ctx->part_done) (void)hipEventDestroy(ev);
         if (ctx->copies_done) (void)hipEventDestroy(ctx->copies_done);
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -622,7 +645,7 @@ static int enqueue_render(rt_ctx* ctx, const rt_params* p, hipStream_t stream, v
     const bool tree = use_tree(ctx, p);
     if (a.tiles_x > 0 && a.tiles_y > 0 && (tree || rt::stack_global_entries(a.max_depth) > 0)) {
         if (!ws && (rc = stream_workspace(ctx, stream, rt::stack_global_entries(a.max_depth) > 0, &ws)) != RT_OK) return rc;
-        if ((rc = attach_workspace(ctx, &a, 1, static_cast<long long>(a.tiles_x) * a.tiles_y, a.max_depth, ws, stream,
+        if ((rc = attach_workspace(ctx, &a, 1, static_cast<long long>(a.tiles_x) * a.tiles_y, a.max_depth, ws,
                                    &deep_blocks)) != RT_OK)
             return rc;
     }
@@ -710,7 +733,7 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
             void* ws = nullptr;
             int rcg = stream_workspace(first, stream, rt::stack_global_entries(depth) > 0, &ws);
             if (rcg == RT_OK)
-                rcg = attach_workspace(first, b.a, live, tiles, depth, ws, static_cast<hipStream_t>(stream), &deep_blocks);
+                rcg = attach_workspace(first, b.a, live, tiles, depth, ws, &deep_blocks);
             if (rcg != RT_OK) return rcg;
         }
         RT_HIP_TRY(first, rt::launch_whitted_batch(b, live, tree, grid, deep_blocks, static_cast<hipStream_t>(stream)));
@@ -873,7 +896,12 @@ int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id, ui
     if (!hit_id && !hit_mask && !spawn_mask) {
         // the image alone: rendered in parts, each copied while the next one is rendered
         const size_t band_bytes = static_cast<size_t>(p->band_rows) * p->width * 3;
-        if ((rc = enqueue_render_to_host(ctx, *p, bgr, band_bytes, d_counters)) != RT_OK) return rc;
+        if ((rc = enqueue_render_to_host(ctx, *p, bgr, band_bytes, d_counters)) != RT_OK) {
+            // copies of earlier parts may still be writing into the caller's buffer
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ctx->copy_stream);
+            return rc;
+        }
         if (count) {
             RT_HIP_TRY(ctx, hipMemcpyAsync(counters, ctx->counters.ptr, sizeof(rt_counters), hipMemcpyDeviceToHost, ctx->stream));
             RT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -1176,8 +1176,9 @@ constexpr int kRefillMin = RT_REFILL_MIN;
 struct TileQueue {
     CArgs* renders;
     const RT_CONST int32_t* tile_end;   // running totals of the renders' tiles; null = one render
-    unsigned int* queue;
+    unsigned int* queue;       // [0] next tile to hand out, [1] waves of the launch that have finished
     int n_tiles;
+    int n_waves;               // waves of the launch
     int cur = 0;               // render of the walking lanes
     int tile = 0, tiles_left = 0;  // tiles in hand: tile, tile+1, ... (not yet started)
     int pos = 64;              // next pixel of the current tile, 64 = used up
@@ -1413,6 +1414,16 @@ __device__ __forceinline__ void trace_queue(TileQueue& feed, double* stk, double
     }
 #undef RT_STACK_IN_LDS
 #undef RT_WALK_FINISHED
+    // The last wave of the launch to finish puts the queue back to zero for the next launch
+    // that uses it (launches that share a queue run one after the other), so the host never
+    // has to clear it.
+    if (lane == 0) {
+        const unsigned int done = atomicAdd(feed.queue + 1, 1u);
+        if (done == (unsigned int)feed.n_waves - 1u) {
+            __hip_atomic_store(feed.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(feed.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 #undef RT_EVENT
 #undef RT_WALK_COUNTERS

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         feed.tile_end = nullptr;
         feed.queue = a.tile_queue;
         feed.n_tiles = a.tiles_x * a.tiles_y;
+        feed.n_waves = (int)gridDim.x * kWavesPerBlock;
         trace_queue<MW, COUNT, TREE, DEEP, LATE, GRID>(feed, stk, gstk, lane, cnt);
     } else {
         const int tx = blockIdx.x * kWavesPerBlock + wave;  // a block = 4 tiles side by side
@@ -121,6 +122,7 @@ void whitted_batch_kernel(KBatch, int n) {
         feed.tile_end = b.tile_end;
         feed.queue = b.a[0].tile_queue;
         feed.n_tiles = b.tile_end[n - 1];
+        feed.n_waves = (int)gridDim.x * kWavesPerBlock;
         trace_queue<0, false, TREE, DEEP, LATE, GRID>(feed, stk, gstk, lane, cnt);
     } else {
         CArgs& a = b.a[blockIdx.z];

@@ -212,6 +212,39 @@ def test_render_device_under_graph_capture(tracer):
             assert np.array_equal(o.cpu().numpy(), tracer.render(p, want_ids=False, want_masks=False)["bgr"])
 
 
+def test_sphere_tree_scene_under_graph_capture(tracer):
+    """A scene that is rendered through the sphere tree (40 spheres or more) takes its tiles
+    from a queue, whose 256 bytes come from a pool the context allocated at rt_create: the
+    render and the batched render are captured on a stream the context has never seen,
+    without a warm-up launch, and replayed."""
+    import torch
+
+    from raytracer_amd.device import BatchPlan, DeviceTracer
+
+    prims, lights = scenes.random_spheres_scene(64, 3, seed=0x64)
+    dev = torch.device("cuda", 0)
+    with DeviceTracer(0) as fresh:            # a context that has not launched anything yet
+        fresh.upload_scene(prims, lights)
+        ps = [abi.make_params(256, 160, d) for d in (3, 5, 4, 5)]
+        outs = [torch.zeros((160, 256, 3), dtype=torch.uint8, device=dev) for _ in ps]
+        plan = BatchPlan([fresh] * 2, ps[2:], [o.data_ptr() for o in outs[2:]])
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            st = torch.cuda.current_stream().cuda_stream
+            fresh.render_device(ps[0], st, outs[0].data_ptr())
+            fresh.render_device(ps[1], st, outs[1].data_ptr())
+            plan.launch(st)
+        for _ in range(2):
+            for o in outs:
+                o.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            for p, o in zip(ps, outs):
+                assert np.array_equal(o.cpu().numpy(), fresh.render(p, want_ids=False, want_masks=False)["bgr"])
+                assert int(o.max().item()) > 0
+
+
 def test_strip_exchange_over_rccl_single_rank(tracer):
     """The multi-GPU step's call sequence on one GPU: an RCCL process group of one rank,
     batched launch into the send buffer, all_to_all_single (async) on device tensors,
