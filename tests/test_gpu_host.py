@@ -57,6 +57,26 @@ def test_cpp_host_program_other_scenes(tmp_path, scene, depth, orbit):
     assert_parity(dict(bgr=frame.read_bmp(out)), ora, f"rt_main {scene}")
 
 
+@pytest.mark.parametrize("scene,size,depth,band_rows", [("default", (640, 363), 5, 8), ("glass", (160, 100), 8, 5)])
+def test_cpp_strip_gather_over_rccl(tmp_path, scene, size, depth, band_rows):
+    """rt_gather = the multi-GPU single-frame path from C++ (one process, one RCCL communicator
+    per GPU of the box: strips rendered with rt_render_device into the buffers ncclGather sends,
+    bands put back in frame order on the host): its frame equals rt_main's of the same
+    configuration, byte for byte."""
+    exe = os.path.join(ROOT, "raytracer_amd", "host", "rt_gather")
+    ref = os.path.join(ROOT, "raytracer_amd", "host", "rt_main")
+    assert os.path.exists(exe), "build raytracer_amd/host first (__graft_entry__.build())"
+    got, want = str(tmp_path / "g.bmp"), str(tmp_path / "m.bmp")
+    common = ["--scene", scene, "--width", str(size[0]), "--height", str(size[1]), "--depth", str(depth)]
+    r = subprocess.run([exe] + common + ["--band-rows", str(band_rows), "--frames", "2", "--out", got],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Gather:" in r.stdout
+    r = subprocess.run([ref] + common + ["--out", want], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(frame.read_bmp(got), frame.read_bmp(want))
+
+
 def test_render_device_on_torch_stream(tracer):
     import torch
 
