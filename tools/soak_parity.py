@@ -77,7 +77,7 @@ def main():
         seed += 1
         if done % 20 == 0:
             print(f"{done} scenes, {pixels} pixels, {time.time() - t0:.0f} s, next seed {seed}", flush=True)
-    print(f"soak ok: {done} scenes, {pixels} pixels x 4 modes, seeds up to {seed - 1}; small frames below 99.9 % "
+    print(f"soak ok: {done} scenes, {pixels} pixels x 8 renders (4 object-loop modes, full and pruned ray tree), seeds up to {seed - 1}; small frames below 99.9 % "
           f"identical pixels held {off_by_one} pixels off by one")
 
 
