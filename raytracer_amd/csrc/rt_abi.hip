@@ -178,9 +178,10 @@ int stream_workspace(rt_ctx* ctx, void* stream, bool deep, void** out) {
 // Point the arguments of a launch with a fixed grid at workspace `ws` and work out the grid
 // size.  The tile queue at the head of the workspace is zero whenever no launch is using
 // it: zeroed when the workspace is made, and put back to zero by the last wave of every launch.
-int attach_workspace(rt_ctx* ctx, rt::KArgs* args, int n, long long tiles, int max_depth, void* ws, int* deep_blocks) {
+int attach_workspace(rt_ctx* ctx, rt::KArgs* args, int n, long long tiles, int max_depth, bool grid, void* ws,
+                     int* deep_blocks) {
     const bool deep = rt::stack_global_entries(max_depth) > 0;
-    *deep_blocks = rt::deep_grid_blocks(ctx->n_cus, tiles, deep);
+    *deep_blocks = rt::deep_grid_blocks(ctx->n_cus, tiles, deep, grid);
     for (int i = 0; i < n; ++i) {
         args[i].tile_queue = static_cast<unsigned int*>(ws);
         args[i].gstack = deep ? reinterpret_cast<double*>(static_cast<char*>(ws) + rt::kWorkspaceHeader) : nullptr;
@@ -645,8 +646,8 @@ static int enqueue_render(rt_ctx* ctx, const rt_params* p, hipStream_t stream, v
     const bool tree = use_tree(ctx, p);
     if (a.tiles_x > 0 && a.tiles_y > 0 && (tree || rt::stack_global_entries(a.max_depth) > 0)) {
         if (!ws && (rc = stream_workspace(ctx, stream, rt::stack_global_entries(a.max_depth) > 0, &ws)) != RT_OK) return rc;
-        if ((rc = attach_workspace(ctx, &a, 1, static_cast<long long>(a.tiles_x) * a.tiles_y, a.max_depth, ws,
-                                   &deep_blocks)) != RT_OK)
+        if ((rc = attach_workspace(ctx, &a, 1, static_cast<long long>(a.tiles_x) * a.tiles_y, a.max_depth, use_grid(ctx, p),
+                                   ws, &deep_blocks)) != RT_OK)
             return rc;
     }
     const rt::SkyTable* sky = nullptr;
@@ -733,7 +734,7 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
             void* ws = nullptr;
             int rcg = stream_workspace(first, stream, rt::stack_global_entries(depth) > 0, &ws);
             if (rcg == RT_OK)
-                rcg = attach_workspace(first, b.a, live, tiles, depth, ws, &deep_blocks);
+                rcg = attach_workspace(first, b.a, live, tiles, depth, grid, ws, &deep_blocks);
             if (rcg != RT_OK) return rcg;
         }
         RT_HIP_TRY(first, rt::launch_whitted_batch(b, live, tree, grid, deep_blocks, static_cast<hipStream_t>(stream)));

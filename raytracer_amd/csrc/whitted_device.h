@@ -149,14 +149,18 @@ static_assert(sizeof(KArgs) % 8 == 0 && alignof(KArgs) == 8 && alignof(SkyTable)
 // queue (one atomic add per tile) until it is empty, so the workspace holds one region per
 // wave of that grid whatever the frame size: 52.5 MiB for the full grid at max_depth 8.
 constexpr int kStackLdsEntries = 2;
+#ifndef RT_STACK_REG_ENTRIES
+#define RT_STACK_REG_ENTRIES 1
+#endif
+constexpr int kStackRegEntries = RT_STACK_REG_ENTRIES;  // deep-stack launches: entries kept in registers
 __host__ __device__ inline int stack_entries(int max_depth) { return max_depth > 2 ? max_depth - 2 : 0; }
 __host__ __device__ inline int stack_lds_entries(int max_depth) {
-    const int e = stack_entries(max_depth) - 1;
+    const int e = stack_entries(max_depth) - kStackRegEntries;
     return e < 0 ? 0 : (e > kStackLdsEntries ? kStackLdsEntries : e);
 }
 __host__ __device__ inline int stack_global_entries(int max_depth) {
-    const int e = stack_entries(max_depth) - 1 - kStackLdsEntries;
-    return e < 0 ? 0 : e;
+    if (stack_entries(max_depth) <= kStackLdsEntries + 1) return 0;  // fits the layout of one-tile launches
+    return stack_entries(max_depth) - kStackRegEntries - kStackLdsEntries;
 }
 // Bytes of dynamic LDS one block needs for a given max_depth.
 inline size_t stack_lds_bytes(int max_depth) {
@@ -179,14 +183,17 @@ constexpr int kDeepMaxBlocks = 1280;      // 256 CUs x 5 resident blocks of 4 wa
 constexpr int kDeepBlocksPerCu = 5;
 constexpr size_t kWorkspaceHeader = 256;
 constexpr size_t kDeepRegionBytes =       // per wave, at RT_MAX_DEPTH
-    (size_t)(RT_MAX_DEPTH - 3 - kStackLdsEntries) * kStackFields * 64 * sizeof(double);
+    (size_t)(RT_MAX_DEPTH - 2 - kStackRegEntries - kStackLdsEntries) * kStackFields * 64 * sizeof(double);
 constexpr size_t kWorkspaceMaxBytes = kWorkspaceHeader + (size_t)kDeepMaxBlocks * kWavesPerBlock * kDeepRegionBytes;
 // Launches with a queue but without the global stack (sphere-tree scenes at max_depth <= 5)
 // fit five waves per SIMD: five blocks per CU.
 constexpr int kQueueBlocksPerCu = 5;
 constexpr int kQueueMaxBlocks = 256 * kQueueBlocksPerCu;
-inline int deep_grid_blocks(int n_cus, long long tiles, bool deep = true) {
-    long long g = (long long)n_cus * (deep ? kDeepBlocksPerCu : kQueueBlocksPerCu);
+// Launches that use the anchor grids are compiled for four waves per SIMD (128 registers: the
+// per-lane list walk does not fit 96 without spilling): four blocks per CU.
+constexpr int kGridBlocksPerCu = 4;
+inline int deep_grid_blocks(int n_cus, long long tiles, bool deep = true, bool grid = false) {
+    long long g = (long long)n_cus * (grid ? kGridBlocksPerCu : (deep ? kDeepBlocksPerCu : kQueueBlocksPerCu));
     const long long cap = deep ? kDeepMaxBlocks : kQueueMaxBlocks;
     if (g > cap) g = cap;
     const long long need = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;

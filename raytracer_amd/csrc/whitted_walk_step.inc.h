@@ -156,16 +156,16 @@
 #pragma unroll
                             for (int f = 0; f < kStackFields; ++f) last_entry[f] = ent[f];
                         }
-                    } else if (sp == 0) {
+                    } else if (sp < kStackRegEntries) {
 #pragma unroll
                         for (int f = 0; f < kStackFields; ++f) bottom[f] = ent[f];
                     } else {
-                        if (!DEEP || sp <= kStackLdsEntries) {
-                            double* e = stk + (size_t)(sp - 1) * kStackFields * 64;
+                        if (!DEEP || sp < kStackRegEntries + kStackLdsEntries) {
+                            double* e = stk + (size_t)(sp - kStackRegEntries) * kStackFields * 64;
 #pragma unroll
                             for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
                         } else {
-                            double* e = gstk + (size_t)(sp - 1 - kStackLdsEntries) * kStackFields * 64 + lane;
+                            double* e = gstk + (size_t)(sp - kStackRegEntries - kStackLdsEntries) * kStackFields * 64 + lane;
 #pragma unroll
                             for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
                         }
@@ -199,16 +199,16 @@
 #pragma unroll
                         for (int f = 0; f < kStackFields; ++f) ent[f] = last_entry[f];
                     }
-                } else if (sp == 0) {
+                } else if (sp < kStackRegEntries) {
 #pragma unroll
                     for (int f = 0; f < kStackFields; ++f) ent[f] = bottom[f];
                 } else {
-                    if (!DEEP || sp <= kStackLdsEntries) {
-                        const double* e = stk + (size_t)(sp - 1) * kStackFields * 64;
+                    if (!DEEP || sp < kStackRegEntries + kStackLdsEntries) {
+                        const double* e = stk + (size_t)(sp - kStackRegEntries) * kStackFields * 64;
 #pragma unroll
                         for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
                     } else {
-                        const double* e = gstk + (size_t)(sp - 1 - kStackLdsEntries) * kStackFields * 64 + lane;
+                        const double* e = gstk + (size_t)(sp - kStackRegEntries - kStackLdsEntries) * kStackFields * 64 + lane;
 #pragma unroll
                         for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
                     }
