@@ -102,6 +102,13 @@ typedef struct rt_light {
                                  partition) which 8x8 tiles no primary ray can hit anything
                                  in, and those tiles get the background colour
                                  (src/main.cc:49-53) untraced; the image is the same.     */
+#define RT_FLAG_NOFRONT 128u  /* walk every pixel in double precision.  Without it an
+                                 image-only render of a small scene (depth <= 5) finishes the
+                                 pixels whose primary ray ends its ray tree - it misses
+                                 everything, or hits one plane with reflectivity 0 and
+                                 transparency 0 - in single precision when every test on the
+                                 way is certain at that precision: same hits and occluders,
+                                 colours within the tolerance of the colour chain.        */
 
 /*
  * Per-render parameters: the values the reference hard-wires in Tracer()/main()

@@ -26,6 +26,7 @@ RT_FLAG_PRUNE = 8
 RT_FLAG_NOGRID = 16
 RT_FLAG_GRID = 32
 RT_FLAG_NOSKY = 64
+RT_FLAG_NOFRONT = 128
 
 PRIM_DTYPE = np.dtype(
     [

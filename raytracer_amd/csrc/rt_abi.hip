@@ -53,6 +53,8 @@ struct rt_ctx {
     int32_t grid_res = 0;
     float grid_eray_max = 0.0f;
     float* d_ltab = nullptr;   // light-anchored line-test constants, n_lights x ltab_stride x 4
+    float* d_front = nullptr;  // KArgs::front; null = scene too large for that pass
+    int32_t n_front = 0;
     int32_t ltab_stride = 0;
     // grow-only device staging for rt_render's host outputs
     DevBuf bgr, hit_id, hit_mask, spawn_mask, counters, dbg_in, dbg_t, dbg_hit, dbg_unit;
@@ -204,6 +206,10 @@ bool use_tree(const rt_ctx* ctx, const rt_params* p) {
 // The anchor grids pay from a handful of spheres on (each feeler then tests the spheres of one
 // cell instead of all of them).
 constexpr int kGridMinSpheres = 8;
+// Scenes with at most this many spheres get the records of the primary-only pass (it tests every
+// sphere of the scene; launches with more spheres than kGridMinSpheres do not run it anyway
+// unless the caller switches the grids off).
+constexpr size_t kFrontMaxSpheres = 16, kFrontMaxPlanes = 8;
 bool use_grid(const rt_ctx* ctx, const rt_params* p) {
     if (!ctx->d_grid_cells || (p->flags & RT_FLAG_NOGRID)) return false;
     if (p->flags & RT_FLAG_GRID) return true;
@@ -230,6 +236,8 @@ int make_args(rt_ctx* ctx, const rt_params* p, rt::KArgs& a) {
     a.grid_eray_max = ctx->grid_eray_max;
     a.ltab = ctx->d_ltab;
     a.ltab_stride = ctx->ltab_stride;
+    a.front = (p->flags & RT_FLAG_NOFRONT) ? nullptr : ctx->d_front;
+    a.n_front = ctx->n_front;
     a.scene_p1max = ctx->scene_p1max;
     a.n_prims = ctx->n_prims;
     a.n_lights = ctx->n_lights;
@@ -355,6 +363,7 @@ void rt_destroy(rt_ctx* ctx) {
         if (ctx->f_planes) (void)hipFree(ctx->f_planes);
         if (ctx->d_planes_before) (void)hipFree(ctx->d_planes_before);
         if (ctx->d_ltab) (void)hipFree(ctx->d_ltab);
+        if (ctx->d_front) (void)hipFree(ctx->d_front);
         if (ctx->d_grid_cells) (void)hipFree(ctx->d_grid_cells);
         if (ctx->d_grid_entries) (void)hipFree(ctx->d_grid_entries);
         free_workspaces(ctx);
@@ -539,9 +548,89 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
         }
         rt::build_anchor_grids(gs, anchors, 256.0 * static_cast<double>(p1max), res, size_t(8) << 20, &grids);
     }
+    // the table of the pass that finishes pixels ending at the primary ray (FrontPlane /
+    // FrontAnchor in whitted_device.h): small scenes only, the pass tests every object
+    std::vector<float> front;
+    const bool want_front = tsph.size() <= kFrontMaxSpheres && fplanes.size() <= kFrontMaxPlanes;
+    if (want_front) {
+        auto put = [&front](const void* rec, size_t bytes) {
+            const size_t at = front.size();
+            front.resize(at + bytes / sizeof(float));
+            std::memcpy(&front[at], rec, bytes);
+        };
+        size_t n_fp = 0;
+        for (int i = 0; i < n_prims; ++i) {
+            if (prims[i].type != RT_PRIM_PLANE) continue;
+            const rt_prim& s = prims[i];
+            rt::FrontPlane fp;
+            std::memset(&fp, 0, sizeof fp);
+            const double hd = s.p[0] * s.q[0] + s.p[1] * s.q[1] + s.p[2] * s.q[2];
+            for (int c = 0; c < 3; ++c) {
+                fp.n[c] = static_cast<float>(mat[i].plane_normal[c]);
+                fp.n_lo[c] = static_cast<float>(s.q[c] - static_cast<double>(fp.n[c]));
+                fp.kd[c] = mat[i].kd[c];
+            }
+            fp.ends = (mat[i].reflectivity == 0.0f && mat[i].transparency == 0.0f) ? 1.0f : 0.0f;
+            fp.h = fgeom[i].v[4];
+            fp.herr = fgeom[i].v[5];
+            fp.h_lo = static_cast<float>(hd - static_cast<double>(fp.h));
+            fp.index = i;
+            fp.transparency = static_cast<float>(s.transparency);
+            fp.ambient = mat[i].ambient_intensity;
+            put(&fp, sizeof fp);
+            ++n_fp;
+        }
+        if (n_fp & 1) {
+            rt::FrontPlane fp;
+            std::memset(&fp, 0, sizeof fp);
+            fp.index = 0x7fffffff;
+            put(&fp, sizeof fp);
+        }
+        for (int ai = 0; ai <= n_lights; ++ai) {
+            rt::FrontAnchor fa;
+            std::memset(&fa, 0, sizeof fa);
+            if (ai < n_lights)
+                for (int c = 0; c < 3; ++c) {
+                    fa.pos[c] = lt[ai].pos[c];
+                    fa.ci[c] = lt[ai].ci[c];
+                }
+            put(&fa, sizeof fa);
+            size_t n_e = 0;
+            for (const rt::TreeSphere& t : tsph) {  // container order
+                const double L[3] = {t.c[0] - fa.pos[0], t.c[1] - fa.pos[1], t.c[2] - fa.pos[2]};
+                rt::GridEntry e;
+                std::memset(&e, 0, sizeof e);
+                float rec[4], cold[2];
+                rt::line_test_record(L, prims[t.index].q[0] * prims[t.index].q[0], rec, cold);
+                e.l[0] = rec[0]; e.l[1] = rec[1]; e.l[2] = rec[2];
+                e.thr = rec[3];
+                e.index = t.index;
+                e.r2 = cold[0];
+                e.ehit = cold[1];
+                e.transparency = static_cast<float>(prims[t.index].transparency);
+                put(&e, sizeof e);
+                ++n_e;
+            }
+            for (; n_e < 2 || (n_e & 1); ++n_e) {  // entries that never hit
+                rt::GridEntry e;
+                std::memset(&e, 0, sizeof e);
+                e.thr = INFINITY;
+                e.index = 0x7fffffff;
+                put(&e, sizeof e);
+            }
+        }
+    }
     DeviceGuard guard(ctx->device);
     RT_HIP_TRY(ctx, guard.status);
     ctx->have_scene = false;
+    if (ctx->d_front) RT_HIP_TRY(ctx, hipFree(ctx->d_front));
+    ctx->d_front = nullptr;
+    ctx->n_front = 0;
+    if (want_front) {
+        RT_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_front), front.size() * sizeof(float)));
+        RT_HIP_TRY(ctx, hipMemcpy(ctx->d_front, front.data(), front.size() * sizeof(float), hipMemcpyHostToDevice));
+        ctx->n_front = static_cast<int32_t>(tsph.size());
+    }
     if (ctx->d_grid_cells) RT_HIP_TRY(ctx, hipFree(ctx->d_grid_cells));
     ctx->d_grid_cells = nullptr;
     if (ctx->d_grid_entries) RT_HIP_TRY(ctx, hipFree(ctx->d_grid_entries));

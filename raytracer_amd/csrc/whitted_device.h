@@ -6,6 +6,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/rt_hip.h"
@@ -77,6 +78,30 @@ struct GridEntry {
 };
 static_assert(sizeof(GridCell) == 8 && sizeof(GridEntry) == 32, "record size");
 
+// The table of the pass that finishes pixels ending at the primary ray (primary_only_pixel() in
+// whitted_exact.inc.h; small scenes only - the pass tests every object):
+//   FrontPlane x (n_planes rounded up to even)
+//   per anchor - the lights in order, then the camera: FrontAnchor, then one GridEntry per sphere
+//   of the scene in container order, rounded up to an even number (at least two) with entries that
+//   never hit (thr = +inf, index = INT_MAX).
+struct FrontPlane {
+    float n[3];              // the plane's normal as the shading uses it: float(calcNormal's result)
+    float ends;              // 1 = reflectivity 0 and transparency 0: a hit spawns no child that is walked
+    float h, herr;           // as in FGeom: float(origin . normal), and its error bound
+    int32_t index;           // position in the caller's object list
+    float transparency;
+    float n_lo[3], h_lo;     // normal_ (double) - n and origin . normal_ (double) - h, rounded to float
+    float kd[3];
+    float ambient;
+};
+struct FrontAnchor {
+    double pos[3];           // the light (camera: zero)
+    float ci[3];             // DLight::ci
+    float pad[7];
+};
+constexpr int kFrontPlaneDwords = 16, kFrontAnchorDwords = 16;
+static_assert(sizeof(FrontPlane) == 4 * kFrontPlaneDwords && sizeof(FrontAnchor) == 4 * kFrontAnchorDwords, "record size");
+
 // Per-lane stack entry: origin xyz, direction xyz, and one field that holds the path weight
 // (float) and the node number.
 constexpr int kCounters = 10;  // fields of rt_counters
@@ -86,6 +111,24 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kTile = 8;  // a wave renders an 8x8 pixel tile
 
 struct KArgs {
+    // ---- the first kFrontArgDwords dwords: everything primary_only_pixel() reads, fetched by
+    // its waves in one go (FrontArgs in whitted_exact.inc.h mirrors this block)
+    const float* front;        // small scenes: the table primary_only_pixel() reads (FrontPlane,
+                               // FrontAnchor below); null = that pass is off
+    uint8_t* bgr;
+    double pw, ph;             // pixel pitch (src/view_frustum.h:33-34)
+    int32_t n_planes, n_front; // planes of the scene; spheres of the scene (records per anchor in
+                               // `front`, before rounding up)
+    int32_t n_lights, width;
+    int32_t height;
+    int32_t rows;              // rows of the strip after clipping
+    int32_t band_rows, band_first, band_step;
+    uint32_t band_magic;       // ceil(2^32 / band_rows): k / band_rows = mulhi(k, band_magic), k < 2^16
+    float scene_p1max;         // >= |centre|_1 of every sphere (filter bound)
+    int32_t sky_unit_shift;    // see SkyTable
+    float bgr_c[3];            // background colour
+    int32_t max_depth;
+    // ---- the rest
     const DGeom* geom;
     const DMat* mat;
     const DLight* lights;
@@ -95,38 +138,34 @@ struct KArgs {
     const int32_t* planes_before;  // [n_prims + 1]: number of planes with a smaller index
     double* gstack;            // global part of the stack: one region per wave of the launch
                                // (stack_workspace_bytes), null if unused
-    unsigned int* tile_queue;  // deep-stack launches: the next tile to hand out (zeroed before
-                               // every launch), null otherwise
+    unsigned int* tile_queue;  // launches with a fixed grid: [0] the next tile to hand out, [1] waves
+                               // that have finished (both zero between launches), null otherwise
     const GridCell* grid_cells;    // anchor grids: [anchor][face][v][u], anchors = the lights, then the
     const GridEntry* grid_entries; // camera; null = not built
     const float* ltab;         // per light, ltab_stride records {c - P (xyz), threshold}: see
                                // line_miss_from_light(); planes carry threshold -inf
-    uint8_t* bgr;
     int32_t* hit_id;
     uint32_t* hit_mask;
     uint32_t* spawn_mask;
     unsigned long long* counters;  // kCounters x u64, same order as rt_counters
-    int32_t n_prims, n_lights;
-    int32_t n_nodes, n_planes;
+    int32_t n_prims;
+    int32_t n_nodes;
     int32_t ltab_stride;       // records per light: n_prims rounded up to a multiple of 4
-    int32_t width, height, max_depth;
-    int32_t band_rows, band_first, band_step;
-    int32_t rows;              // rows of the strip after clipping
     int32_t tiles_x, tiles_y;  // 8x8 tiles covering width x rows
     int32_t mask_words;
-    double pw, ph;             // pixel pitch (src/view_frustum.h:33-34)
-    float bgr_c[3];            // background colour
     float inv_depth[RT_MAX_DEPTH + 1];  // 1.0/depth for depth 1..max_depth-1
-    float scene_p1max;         // >= |centre|_1 of every sphere (filter bound)
-    uint32_t band_magic;       // ceil(2^32 / band_rows): k / band_rows = mulhi(k, band_magic), k < 2^16
     int32_t primary_in_range;  // every primary ray's p1 passes the range guard of unit()
     int32_t grid_res;          // cells per face edge
     float grid_half;           // grid_res / 2
     float grid_eray_max;       // the grids hold for rays whose FilterRay::eray is at most this
-    int32_t sky_unit_shift;    // see SkyTable
     int32_t prune;             // ids, masks and counters describe the walk without the children of
                                // weight zero (the image-only kernels always leave those out)
 };
+constexpr int kFrontArgDwords = 24;
+static_assert(offsetof(KArgs, front) == 0 && offsetof(KArgs, bgr) == 8 && offsetof(KArgs, pw) == 16 &&
+                  offsetof(KArgs, n_planes) == 32 && offsetof(KArgs, band_magic) == 68 && offsetof(KArgs, bgr_c) == 80 &&
+                  offsetof(KArgs, max_depth) == 92 && offsetof(KArgs, geom) == 4 * kFrontArgDwords,
+              "FrontArgs reads the head of KArgs by position");
 
 // Screen bounds of the scene for launches with one wave per tile (sky_table.h): tile row ty reads
 // cols[min(ty, kSkyRows - 1)] = lo | hi << 8, the range of tile columns - in units of

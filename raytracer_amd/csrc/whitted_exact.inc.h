@@ -1306,6 +1306,281 @@ __device__ __forceinline__ void store_pixel(AT& a, int x, int k, float cr, float
     }
 }
 
+// ---- pixels that end at the primary ray, in single precision ---------------------------------
+// A primary ray that certainly misses every object gives the background.  One that certainly
+// hits exactly one object, a plane whose material has reflectivity 0 and transparency 0, ends
+// at that hit as well when only the image is asked for (children under a coefficient of zero
+// are left out): the pixel is the plane's own shade, src/objects.h:20-65 at depth 1.  Nothing
+// computed for such a pixel decides anything but colours, PROVIDED every decision on the way is
+// certain: the primary ray's tests (classify_plane; the line test from the camera's records for
+// the spheres) and, per light, the first occluder of the shadow feeler (classify_plane /
+// classify_sphere over all objects in container order).  Such a pixel is finished here without
+// the double-precision walk.  A lane that meets a single test that is not certain leaves the
+// pass without a result and is walked as usual; whether a lane qualifies depends on its own
+// pixel only, so a pixel does not depend on its neighbours or on how the frame is cut.
+//
+// The hit point.  For the un-normalised pixel vector v (src/view_frustum.h:37-46, exact in
+// double) and the plane (p0, n), h = p0.n: ip = v h / (v.n), the reference's o + d t for o = 0
+// up to rounding.  n and h come from the pass's own records as the sum of two floats (2^-48 of
+// their size off the doubles).  The pass only takes planes met at |cos| = |v.n| / |v| > 1e-3;
+// then v.n is within 6.8e-12 of itself (2^-48 sqrt(3) |v| from the records, 3 x 2^-53 |v|_1 from
+// the sums, over |v| 1e-3) and h within 3.9e-15 |p0|_1, so this ip lies within
+// 7e-12 (|ip| + |p0|_1) of the exact intersection, the reference's own within 1.2e-12 of it.
+// A feeler at distance dist >= 1e-3 (|ip|_1 + |p0|_1) from its light turns by less than 8.2e-9
+// for that, inside the slack of feel_ray()'s direction bound (its steps add up to
+// 5.5 x 2^-24 = 3.28e-7 of the 3.6e-7 allowed); the shift of the origin itself is added to the
+// bounds of the origin-dependent tests (en_ray, efront) as 1e-11 (|ip|_1 + |p0|_1).  |p0|_1 is
+// taken from the plane's record: herr = 1.01 U (|h| + |p0|_1).
+//
+// A wave of this pass is short, and what its time would consist of is the chain of scalar loads
+// it waits for one after the other (measured: 700 cycles each, 20 of them when the compiler
+// places them - it fetches every kernel argument and record where it is first used).  So the
+// pass fetches in three stages and holds the values in scalar registers from there on
+// (RT_HOLD): its arguments (the head of KArgs, FrontArgs) together with the tile's screen
+// bounds; the first plane and the camera's first two sphere records; per light its position,
+// colour and first two sphere records.  A scene with more planes or spheres adds a load per
+// further record.
+#define RT_HOLD1(a) "+s"(a)
+#define RT_HOLD4(w, o) RT_HOLD1(w[o]), RT_HOLD1(w[o + 1]), RT_HOLD1(w[o + 2]), RT_HOLD1(w[o + 3])
+#define RT_HOLD8(w, o) RT_HOLD4(w, o), RT_HOLD4(w, o + 4)
+
+// The head of KArgs (kFrontArgDwords dwords) in scalar registers.
+struct FrontArgs {
+    uint32_t w[kFrontArgDwords];
+    __device__ __forceinline__ cfdata_t front() const { return (cfdata_t)(const float*)(((uint64_t)w[1] << 32) | w[0]); }
+    __device__ __forceinline__ uint8_t* bgr() const { return (uint8_t*)(((uint64_t)w[3] << 32) | w[2]); }
+    __device__ __forceinline__ double pw() const { return __hiloint2double((int)w[5], (int)w[4]); }
+    __device__ __forceinline__ double ph() const { return __hiloint2double((int)w[7], (int)w[6]); }
+    __device__ __forceinline__ int n_planes() const { return (int)w[8]; }
+    __device__ __forceinline__ int n_front() const { return (int)w[9]; }
+    __device__ __forceinline__ int n_lights() const { return (int)w[10]; }
+    __device__ __forceinline__ int width() const { return (int)w[11]; }
+    __device__ __forceinline__ int height() const { return (int)w[12]; }
+    __device__ __forceinline__ int rows() const { return (int)w[13]; }
+    __device__ __forceinline__ int band_rows() const { return (int)w[14]; }
+    __device__ __forceinline__ int band_first() const { return (int)w[15]; }
+    __device__ __forceinline__ int band_step() const { return (int)w[16]; }
+    __device__ __forceinline__ uint32_t band_magic() const { return w[17]; }
+    __device__ __forceinline__ float scene_p1max() const { return __uint_as_float(w[18]); }
+    __device__ __forceinline__ int sky_unit_shift() const { return (int)w[19]; }
+    __device__ __forceinline__ float bgr_c(int i) const { return __uint_as_float(w[20 + i]); }
+};
+// Fetches the arguments at `kp` (a KArgs in the constant address space) and the word at `extra`
+// with loads that are issued together.
+__device__ __forceinline__ FrontArgs load_front_args(const RT_CONST uint32_t* kp, const RT_CONST uint32_t* extra, uint32_t& extra_word) {
+    FrontArgs f;
+#pragma unroll
+    for (int i = 0; i < kFrontArgDwords; ++i) f.w[i] = kp[i];
+    uint32_t e = *extra;
+    __asm__ volatile("" : RT_HOLD8(f.w, 0), RT_HOLD8(f.w, 8), RT_HOLD8(f.w, 16), RT_HOLD1(e));
+    extra_word = e;
+    return f;
+}
+
+struct FrontState {
+    bool ok;       // every test so far was certain
+    int cur;       // the plane that is hit, -1 = none
+    bool ends;     // its material spawns no child
+    double vq, hd; // v.n and p0.n of that plane
+    float pb;      // >= |p0|_1
+    F3 nf, kd;     // its normal and diffuse colour
+    float amb;
+};
+struct FrontPlaneRec {  // the first half of a FrontPlane in scalar registers
+    float n0, n1, n2, ends, h, herr;
+    int idx;
+    float transp;
+};
+__device__ __forceinline__ FrontPlaneRec front_plane(const uint32_t* w) {
+    FrontPlaneRec r;
+    r.n0 = __uint_as_float(w[0]); r.n1 = __uint_as_float(w[1]); r.n2 = __uint_as_float(w[2]);
+    r.ends = __uint_as_float(w[3]); r.h = __uint_as_float(w[4]); r.herr = __uint_as_float(w[5]);
+    r.idx = (int)w[6];
+    r.transp = __uint_as_float(w[7]);
+    return r;
+}
+__device__ __forceinline__ FRec as_frec(const FrontPlaneRec& r) {
+    FRec g;
+    g.a0 = r.n0; g.a1 = r.n1; g.a2 = r.n2; g.r2 = -1.0f; g.b0 = r.h; g.b1 = r.herr;
+    return g;
+}
+// The primary ray against the plane record in w[0..15].
+__device__ __forceinline__ void front_primary_plane(const uint32_t* w, const FeelRay& pr, V3 v, FrontState& s) {
+    const FrontPlaneRec r = front_plane(w);
+    bool hit;
+    float factor = 0.0f;
+    const bool sure = classify_plane(as_frec(r), 0.0f, pr, hit, factor);
+    s.ok = s.ok & sure & !(hit & (s.cur >= 0));  // (two planes hit: which is nearer is not looked into)
+    if (sure & hit) {
+        s.cur = r.idx;
+        s.ends = r.ends != 0.0f;
+        const V3 q = mk((double)r.n0 + (double)__uint_as_float(w[8]), (double)r.n1 + (double)__uint_as_float(w[9]),
+                        (double)r.n2 + (double)__uint_as_float(w[10]));
+        s.vq = dot(v, q);
+        s.hd = (double)r.h + (double)__uint_as_float(w[11]);
+        s.pb = r.herr * (1.0f / (1.01f * 6.0e-8f));
+        s.nf = f3(r.n0, r.n1, r.n2);
+        s.kd = f3(__uint_as_float(w[12]), __uint_as_float(w[13]), __uint_as_float(w[14]));
+        s.amb = __uint_as_float(w[15]);
+    }
+}
+// The primary ray against the sphere record in w[0..3]: the line misses the sphere, or the
+// sphere lies behind the camera (src/objects.h:128-129).
+__device__ __forceinline__ void front_primary_sphere(const uint32_t* w, const FeelRay& pr, bool& ok) {
+    const float t = __builtin_fmaf(__uint_as_float(w[2]), pr.d.z, __builtin_fmaf(__uint_as_float(w[1]), pr.d.y, __uint_as_float(w[0]) * pr.d.x));
+    ok = ok & ((__builtin_fmaf(-t, t, __uint_as_float(w[3])) > pr.eray) | (t < -pr.efront));
+}
+// A shadow feeler against the plane record in w[0..7] / the sphere record in w[0..7], to be
+// called in container order.
+__device__ __forceinline__ void front_feeler_plane(const uint32_t* w, const FeelRay& fr, int cur, bool& good, int& best, float& occl) {
+    const FrontPlaneRec r = front_plane(w);
+    if (good & (r.idx != cur) & (r.idx < best)) {
+        bool hit;
+        float factor = 0.0f;
+        good = classify_plane(as_frec(r), r.transp, fr, hit, factor);
+        if (good & hit) { best = r.idx; occl = factor; }
+    }
+}
+__device__ __forceinline__ void front_feeler_sphere(const uint32_t* w, const FeelRay& fr, bool& good, int& best, float& occl) {
+    LRec l;
+    l.x = __uint_as_float(w[0]); l.y = __uint_as_float(w[1]); l.z = __uint_as_float(w[2]); l.thr = __uint_as_float(w[3]);
+    const int idx = (int)w[4];
+    const float t = __builtin_fmaf(l.z, fr.d.z, __builtin_fmaf(l.y, fr.d.y, l.x * fr.d.x));
+    if (good & (idx < best) & !(__builtin_fmaf(-t, t, l.thr) > fr.eray)) {
+        bool hit;
+        float factor = 0.0f;
+        good = classify_sphere(l, t, __uint_as_float(w[5]), __uint_as_float(w[6]), __uint_as_float(w[7]), fr, hit, factor);
+        if (good & hit) { best = idx; occl = factor; }
+    }
+}
+template <int N>
+__device__ __forceinline__ void front_load(uint32_t (&w)[N], cfdata_t p) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = __float_as_uint(p[i]);
+}
+// Returns true for the lanes whose pixel has been stored.
+__device__ __forceinline__ bool primary_only_pixel(const FrontArgs& a, const int x, const int k, const bool inside) {
+    const float U = 6.0e-8f;
+    // the table: plane records (an even number of them), then per anchor - the lights, then the
+    // camera - a header and the sphere records (an even number, padded with records that never hit)
+    const cfdata_t planes = a.front();
+    const int n_planes = a.n_planes(), n_spheres = a.n_front();
+    const int planes2 = (n_planes + 1) & ~1, spheres2 = n_spheres > 0 ? ((n_spheres + 1) & ~1) : 2;
+    const cfdata_t anchors = planes + planes2 * kFrontPlaneDwords;
+    const int anchor_stride = kFrontAnchorDwords + spheres2 * 8;
+    const cfdata_t camera = anchors + (size_t)a.n_lights() * anchor_stride + kFrontAnchorDwords;
+    uint32_t p0[16], c0[4], c1[4];
+    front_load(p0, planes);  // (a scene without planes: whatever lies there, not looked at)
+    front_load(c0, camera);
+    front_load(c1, camera + 8);
+    __asm__ volatile("" : RT_HOLD8(p0, 0), RT_HOLD8(p0, 8), RT_HOLD4(c0, 0), RT_HOLD4(c1, 0));
+
+    // src/main.cc:135-138, src/view_frustum.h:37-46: frame row of strip row k, pixel vector
+    const int band = (a.band_rows() == 1) ? k : (int)__umulhi((uint32_t)k, a.band_magic());
+    const int y = (a.band_first() + band * a.band_step()) * a.band_rows() + (k - band * a.band_rows());
+    const V3 v = mk((x - a.width() / 2 + 0.5) * a.pw(), (y - a.height() / 2 + 0.5) * a.ph(), 1.0);
+    // the primary ray as a FeelRay whose anchor (the camera) is its origin: dist = 0
+    FeelRay pr;
+    pr.o = f3(0.0f, 0.0f, 0.0f);
+    const F3 vf = f3((float)v.x, (float)v.y, (float)v.z);
+    const float s2 = dotf(vf, vf);
+    const float inv = __builtin_amdgcn_rsqf(s2);
+    const float vlen = s2 * inv;
+    pr.d = f3(vf.x * inv, vf.y * inv, vf.z * inv);
+    pr.dist = 0.0f;
+    pr.en_ray = 0.0f;
+    pr.eray = 1.0e-13f * a.scene_p1max() * a.scene_p1max();
+    pr.efront = 16.0f * U * a.scene_p1max();
+    pr.valid = true;
+
+    FrontState s;
+    s.ok = inside & (s2 < 1.0e30f);  // (s2 >= 1: the float normalisation keeps its error bound)
+    s.cur = -1;
+    s.ends = false;
+    s.vq = 1.0; s.hd = 0.0; s.pb = 0.0f; s.amb = 0.0f;
+    s.nf = f3(0.0f, 0.0f, 0.0f); s.kd = s.nf;
+    if (n_planes > 0) front_primary_plane(p0, pr, v, s);
+    for (int j = 1; j < n_planes; ++j) {
+        uint32_t pj[16];
+        front_load(pj, planes + j * kFrontPlaneDwords);
+        front_primary_plane(pj, pr, v, s);
+    }
+    front_primary_sphere(c0, pr, s.ok);
+    front_primary_sphere(c1, pr, s.ok);
+    for (int j = 2; j < spheres2; ++j) {
+        uint32_t cj[4];
+        front_load(cj, camera + j * 8);
+        front_primary_sphere(cj, pr, s.ok);
+    }
+    if (!__any(s.ok)) return false;
+
+    float cr = a.bgr_c(0), cg = a.bgr_c(1), cb = a.bgr_c(2);  // nothing hit: src/main.cc:49-53
+    const bool on_plane = s.ok & (s.cur >= 0);
+    // (a plane with children, or one met at a flat angle, is left to the walk)
+    const bool shade = on_plane & s.ends & (__builtin_fabsf((float)s.vq) > 1.1e-3f * vlen);
+    bool ok = s.ok & (shade | !on_plane);
+    if (__any(shade)) {
+        const V3 ip = v * (s.hd * rcp_refined(shade ? s.vq : 1.0));
+        float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+        bool good = shade;
+        cfdata_t anchor = anchors;
+        for (int li = 0; li < a.n_lights(); ++li, anchor += anchor_stride) {
+            uint32_t lw[9], e0[8], e1[8];
+            front_load(lw, anchor);  // FrontAnchor: position (three doubles), colour
+            front_load(e0, anchor + kFrontAnchorDwords);
+            front_load(e1, anchor + kFrontAnchorDwords + 8);
+            __asm__ volatile("" : RT_HOLD8(lw, 0), RT_HOLD1(lw[8]), RT_HOLD8(e0, 0), RT_HOLD8(e1, 0));
+            const V3 lpos = mk(__hiloint2double((int)lw[1], (int)lw[0]), __hiloint2double((int)lw[3], (int)lw[2]),
+                               __hiloint2double((int)lw[5], (int)lw[4]));
+            const F3 ci = f3(__uint_as_float(lw[6]), __uint_as_float(lw[7]), __uint_as_float(lw[8]));
+            FeelRay fr = feel_ray(ip, lpos - ip, a.scene_p1max());
+            const float reach = l1f(fr.o) + s.pb;
+            good = good & fr.valid & (fr.dist > 1.0e-3f * reach);
+            fr.en_ray = __builtin_fmaf(1.0e-11f, reach, fr.en_ray);
+            fr.efront = __builtin_fmaf(1.0e-11f, reach, fr.efront);
+            int best = 0x7fffffff;
+            float occl = 1.0f;
+            if (n_planes > 0) front_feeler_plane(p0, fr, s.cur, good, best, occl);
+            for (int j = 1; j < n_planes; ++j) {
+                uint32_t pj[8];
+                front_load(pj, planes + j * kFrontPlaneDwords);
+                front_feeler_plane(pj, fr, s.cur, good, best, occl);
+            }
+            front_feeler_sphere(e0, fr, good, best, occl);
+            front_feeler_sphere(e1, fr, good, best, occl);
+            for (int j = 2; j < spheres2; ++j) {
+                uint32_t ej[8];
+                front_load(ej, anchor + kFrontAnchorDwords + j * 8);
+                front_feeler_sphere(ej, fr, good, best, occl);
+            }
+            // src/objects.h:50-60, the operations of the walk's shading in the same order
+            const float dk = __builtin_fabsf(dotf(s.nf, fr.d)) * occl;
+            sr = __builtin_fmaxf(__builtin_fmaf(s.kd.x * ci.x, dk, sr), 0.0f);
+            sb = __builtin_fmaxf(__builtin_fmaf(s.kd.z * ci.z, dk, sb), 0.0f);
+            sg = __builtin_fmaxf(__builtin_fmaf(s.kd.y * ci.y, dk, sg), 0.0f);
+        }
+        ok = ok & (good | !on_plane);
+        // own colour at depth 1 (1.0 / depth = 1) with transparency 0 and path weight 1,
+        // src/main.cc:111-112
+        if (on_plane) {
+            cr = __builtin_fmaf(a.bgr_c(0), s.amb, sr);
+            cg = __builtin_fmaf(a.bgr_c(1), s.amb, sg);
+            cb = __builtin_fmaf(a.bgr_c(2), s.amb, sb);
+        }
+    }
+    if (ok) {
+#ifdef RT_FRONT_MARK  // analysis builds: pixels finished by this pass in one colour
+        cr = 1.0f; cg = 0.0f; cb = 1.0f;
+#endif
+        // src/screen.h:62-64, src/color.h:27-29
+        uint8_t* dst = a.bgr() + 3 * ((size_t)k * a.width() + x);
+        dst[0] = (uint8_t)to_u8(cb);
+        dst[1] = (uint8_t)to_u8(cg);
+        dst[2] = (uint8_t)to_u8(cr);
+    }
+    return ok;
+}
+
 // One wave, one 8x8 tile: (x, k) = this lane's column and strip row; `have` is false for
 // lanes without a pixel.
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, bool GRID, typename AT>

@@ -70,20 +70,37 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         const int ty = blockIdx.y;
         const int x = tx * kTile + (lane & 7);
         const int k = ty * kTile + (lane >> 3);  // row in strip order
+        bool have;
         if (MW == 0 && !COUNT) {
             // a tile outside the screen bounds of the scene is background (src/main.cc:49-53)
-            const RT_CONST uint32_t* sky =
-                (const RT_CONST uint32_t*)((const RT_CONST char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(KArgs));
+            const RT_CONST uint32_t* kp = (const RT_CONST uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
+            const RT_CONST uint32_t* sky = (const RT_CONST uint32_t*)((const RT_CONST char*)kp + sizeof(KArgs));
             const uint32_t row = min((uint32_t)ty, (uint32_t)(kSkyRows - 1));
-            const uint32_t rng = sky[row >> 1] >> ((row & 1u) << 4);
-            const uint32_t col = (uint32_t)tx >> a.sky_unit_shift;
+            uint32_t word;
+            // (the arguments the rest of this branch needs, and the bounds, in one fetch)
+            const FrontArgs fa = load_front_args(kp, sky + (row >> 1), word);
+            const uint32_t rng = word >> ((row & 1u) << 4);
+            const uint32_t col = (uint32_t)tx >> fa.sky_unit_shift();
+            have = (x < fa.width()) && (k < fa.rows());
             if (col < (rng & 0xffu) || col > ((rng >> 8) & 0xffu)) {
-                const uint32_t none[1] = {0};
-                if ((x < a.width) && (k < a.rows)) store_pixel<0>(a, x, k, a.bgr_c[0], a.bgr_c[1], a.bgr_c[2], -1, none, none);
+                if (have) {
+                    uint8_t* dst = fa.bgr() + 3 * ((size_t)k * fa.width() + x);
+                    dst[0] = (uint8_t)to_u8(fa.bgr_c(2));
+                    dst[1] = (uint8_t)to_u8(fa.bgr_c(1));
+                    dst[2] = (uint8_t)to_u8(fa.bgr_c(0));
+                }
                 return;
             }
+            // pixels that end at the primary ray are finished in single precision (launches with
+            // the container-order loops and the short stack; KArgs::front null = switched off)
+            if (!TREE && !DEEP && !GRID && fa.front() != nullptr) {
+                have = have & !primary_only_pixel(fa, x, k, have);
+                if (!__any(have)) return;
+            }
+        } else {
+            have = (x < a.width) && (k < a.rows);
         }
-        trace_tile<MW, COUNT, TREE, DEEP, LATE, GRID>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
+        trace_tile<MW, COUNT, TREE, DEEP, LATE, GRID>(a, x, k, have, stk, nullptr, lane, cnt);
     }
     flush_counters<COUNT>(a, cnt, lane);
 }
@@ -135,7 +152,15 @@ void whitted_batch_kernel(KBatch, int n) {
         const int ty = blockIdx.y;
         const int x = tx * kTile + (lane & 7);
         const int k = ty * kTile + (lane >> 3);
-        trace_tile<0, false, TREE, DEEP, LATE, GRID>(a, x, k, (x < a.width) && (k < a.rows), stk, nullptr, lane, cnt);
+        bool have = (x < a.width) && (k < a.rows);
+        if (!GRID && a.front != nullptr) {
+            const RT_CONST uint32_t* kp = (const RT_CONST uint32_t*)&a;
+            uint32_t unused;
+            const FrontArgs fa = load_front_args(kp, kp, unused);
+            have = have & !primary_only_pixel(fa, x, k, have);
+            if (!__any(have)) return;
+        }
+        trace_tile<0, false, TREE, DEEP, LATE, GRID>(a, x, k, have, stk, nullptr, lane, cnt);
     }
 }
 

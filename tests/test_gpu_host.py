@@ -363,13 +363,23 @@ def test_rt_render_in_parts_and_into_page_locked_memory(tracer):
              abi.make_params(1024, 700, 5, band_rows=300, band_first=1, band_step=1, band_count=1),
              abi.make_params(1024, 700, 5, band_rows=400, band_first=0, band_step=1, band_count=1)]
     for p in cases:
-        want = tracer.render(p)["bgr"]                      # one launch, not split
+        ids = tracer.render(p)["bgr"]                       # one launch, not split
+        walked = p.copy()
+        walked["flags"] = abi.RT_FLAG_NOFRONT              # every pixel walked in double precision:
+        assert np.array_equal(tracer.render(walked, want_ids=False, want_masks=False)["bgr"], ids)  # the same bytes
         got = tracer.render(p, want_ids=False, want_masks=False)["bgr"]
-        assert np.array_equal(got, want)
-        hf = HostFrame(want.shape)
+        assert_parity({"bgr": got}, {"bgr": ids}, "image only, in parts")
+        # ... and the same bytes as the image-only render done with one launch
+        import torch
+
+        one = torch.zeros(ids.shape, dtype=torch.uint8, device="cuda")
+        tracer.render_device(p, torch.cuda.current_stream().cuda_stream, one.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(got, one.cpu().numpy())
+        hf = HostFrame(ids.shape)
         hf.array[:] = 3
         tracer.render_into(p, hf.array)
-        assert np.array_equal(hf.array, want)
+        assert np.array_equal(hf.array, got)
         hf.close()
     # a depth-8 frame in parts: every part's launch re-arms the tile queue of the workspace
     tracer.upload_scene(*scenes.glass_scene())

@@ -17,11 +17,18 @@ def _both(tracer, prims, lights, params, counters=True):
         # the counting kernels are separate instantiations: the plain ones (with and without
         # the id/mask outputs) must give the same frame
         plain = tracer.render(params)
-        image_only = tracer.render(params, want_ids=False, want_masks=False)
         for k in ("bgr", "hit_id", "hit_mask", "spawn_mask"):
             assert np.array_equal(plain[k], dev[k]), f"counting and plain kernels differ in {k}"
+        walked = params.copy()
+        walked["flags"] = int(params["flags"]) | abi.RT_FLAG_NOFRONT
+        image_only = tracer.render(walked, want_ids=False, want_masks=False)
         assert np.array_equal(image_only["bgr"], dev["bgr"]), "image-only kernel differs"
     ora = oracle_lib.render(prims, lights, params, want_counters=counters)
+    if counters:
+        # the image-only render as callers get it: pixels that end at the primary ray are
+        # finished in single precision (same hits and occluders, colours to the tolerance)
+        image_only = tracer.render(params, want_ids=False, want_masks=False)
+        assert_parity({"bgr": image_only["bgr"]}, {"bgr": ora["bgr"]}, "image-only")
     return dev, ora
 
 
@@ -188,6 +195,91 @@ def test_screen_bounds(tracer, name):
         assert np.array_equal(fast, slow), (name, int(p["width"]), int(p["band_rows"]))
         skipped += int((fast == fast[-1, 0]).all(axis=-1).sum())
     assert skipped > 0 or name == "inside"
+
+
+@pytest.mark.parametrize("name", ["default", "room", "floor_contacts", "grazing_floor", "crossing_floors", "six_lights",
+                                  "light_on_floor", "far_scene", "no_lights", "tilted_floor"])
+def test_pixels_ending_at_the_primary_ray(tracer, name):
+    """Image-only renders of small scenes finish the pixels whose primary ray ends the ray tree
+    (nothing hit, or one plane with reflectivity 0 and transparency 0) in single precision where
+    every test on the way is certain at that precision.  Against the checker's frame: colours
+    to the tolerance; against the frame walked in double precision (RT_FLAG_NOFRONT): never more
+    than one off; a strip's rows are byte for byte the whole frame's rows."""
+    matte = dict(reflectivity=0.0, transparency=0.0)
+    k = (0.6, 0.6, 0.6)
+    white = (1, 1, 1)
+    lights = [scenes.point_light(white, 0.6, (0, 8, 10)), scenes.point_light((1, 0.9, 0.8), 0.3, (-6, 2, 2))]
+    depth = 5
+    if name == "default":
+        prims, lt = scenes.default_scene()
+        prims, lights = list(prims), None
+    elif name == "room":  # six planes, four of them matte; spheres inside
+        prims = [scenes.plane((0, -3, 0), (0, 1, 0), k, **matte), scenes.plane((0, 9, 0), (0, -1, 0), k, **matte),
+                 scenes.plane((-8, 0, 0), (1, 0.05, 0.1), (0.8, 0.3, 0.3), reflectivity=0.5),
+                 scenes.plane((8, 0, 0), (-1, 0, 0), (0.3, 0.8, 0.3), **matte),
+                 scenes.plane((0, 0, 30), (0.02, 0, -1), (0.3, 0.3, 0.8), reflectivity=0.9),
+                 scenes.plane((0, 0, -1), (0, 0, 1), k, **matte),
+                 scenes.sphere((-2, -1, 12), 2.0, white, reflectivity=0.9, transparency=0.9, refraction_index=1.5),
+                 scenes.sphere((3, 0, 16), 3.0, (0.9, 0.8, 0.2), reflectivity=1.0)]
+    elif name == "floor_contacts":  # spheres resting on, cutting and hovering just above the floor
+        prims = [scenes.plane((0, -3, 0), (0, 1, 0), k, **matte),
+                 scenes.sphere((-4, -2, 12), 1.0, white, reflectivity=0.2, transparency=0.8, refraction_index=1.4),
+                 scenes.sphere((0, -3, 14), 1.5, (0.9, 0.2, 0.2), **matte),
+                 scenes.sphere((4, -1.999999, 10), 1.0, (0.2, 0.9, 0.2), reflectivity=0.6),
+                 scenes.sphere((1, 2, 9), 0.7, white, transparency=1.0, refraction_index=1.1)]
+    elif name == "grazing_floor":  # a floor seen almost edge-on: the pass leaves the flat band to the walk
+        prims = [scenes.plane((0, -0.02, 0), (0, 1, 0.003), k, **matte),
+                 scenes.sphere((0, 1.5, 20), 1.5, (0.9, 0.8, 0.2), reflectivity=0.7)]
+    elif name == "crossing_floors":  # two matte planes in view: a pixel may hit both
+        prims = [scenes.plane((0, -3, 0), (0, 1, 0), k, **matte), scenes.plane((0, 0, 40), (0.3, 0.2, -1), (0.8, 0.4, 0.3), **matte),
+                 scenes.sphere((2, 0, 15), 2.0, white, reflectivity=0.5, transparency=0.5, refraction_index=1.3)]
+    elif name == "six_lights":
+        prims, lt = scenes.glass_scene(n_spheres=5, n_lights=6)
+        prims, lights = list(prims), None
+    elif name == "light_on_floor":  # lights within and under the floor's surface, one next to a sphere
+        prims = [scenes.plane((0, -3, 0), (0, 1, 0), k, **matte), scenes.sphere((0, -1, 12), 2.0, white, reflectivity=0.5)]
+        lights = [scenes.point_light(white, 0.5, (1, -3.0, 8)), scenes.point_light(white, 0.5, (-2, -3.000001, 10)),
+                  scenes.point_light(white, 0.4, (0, -5, 12)), scenes.point_light(white, 0.4, (2.0001, -1, 12))]
+    elif name == "far_scene":  # everything far from the origin: the error bounds scale with the coordinates
+        prims = [scenes.plane((0, -3000, 0), (0, 1, 0), k, **matte), scenes.sphere((500, -1000, 9000), 2000.0, white, reflectivity=0.4),
+                 scenes.sphere((-2500, -2500, 7000), 500.0, (0.3, 0.5, 0.9), transparency=0.7, refraction_index=1.2)]
+        lights = [scenes.point_light(white, 0.7, (0, 8000, 5000)), scenes.point_light(white, 0.3, (-6000, 200, 2000))]
+    elif name == "no_lights":
+        prims = [scenes.plane((0, -3, 0), (0, 1, 0), k, **matte), scenes.sphere((0, 0, 12), 2.0, white, reflectivity=0.5)]
+        lights = []
+    else:  # tilted_floor
+        prims = [scenes.plane((1, -3, 2), (0.3, 1, -0.2), k, **matte), scenes.plane((0, 30, 0), (0, -1, 0.1), (0.2, 0.3, 0.9), **matte),
+                 scenes.sphere((-3, 0, 14), 2.5, white, reflectivity=0.3, transparency=0.6, refraction_index=1.5),
+                 scenes.sphere((4, -1, 11), 1.5, (0.9, 0.5, 0.1), reflectivity=0.2)]
+    if lights is None:
+        lights = lt
+    else:
+        lights = scenes._stack(lights, abi.LIGHT_DTYPE)
+        prims = scenes._stack(prims, abi.PRIM_DTYPE)
+    if not isinstance(prims, np.ndarray):
+        prims = scenes._stack(prims, abi.PRIM_DTYPE)
+    tracer.upload_scene(prims, lights)
+    moved = pixels = 0
+    for p in (abi.make_params(640, 360, depth), abi.make_params(203, 117, 3), abi.make_params(1280, 720, 2)):
+        ora = oracle_lib.render(prims, lights, p, want_ids=False, want_masks=False)
+        fast = tracer.render(p, want_ids=False, want_masks=False)["bgr"]
+        slow = tracer.render(_with_flags(p, abi.RT_FLAG_NOFRONT), want_ids=False, want_masks=False)["bgr"]
+        assert_parity({"bgr": fast}, {"bgr": ora["bgr"]}, f"primary-only pass, {name}")
+        assert_parity({"bgr": slow}, {"bgr": ora["bgr"]}, f"walked, {name}")
+        delta = np.abs(fast.astype(int) - slow.astype(int)).max(axis=-1)
+        assert delta.max() <= 1
+        moved += int(np.count_nonzero(delta))
+        pixels += delta.size
+    assert moved <= pixels // 2000, (name, moved, pixels)
+    # strips: a pixel does not depend on how the frame is cut
+    base = abi.make_params(640, 360, depth)
+    whole = tracer.render(base, want_ids=False, want_masks=False)["bgr"]
+    for band_rows, first, step in ((8, 1, 3), (1, 0, 7), (5, 2, 4)):
+        p = abi.make_params(640, 360, depth, band_rows=band_rows, band_first=first, band_step=step,
+                            band_count=-(-360 // (band_rows * step)))
+        part = tracer.render(p, want_ids=False, want_masks=False)["bgr"]
+        rows = abi.strip_image_rows(p)
+        assert np.array_equal(part, whole[rows]), (name, band_rows, first, step)
 
 
 def test_glass_depth8(tracer):

@@ -1,7 +1,7 @@
 """Kernel time of whole-frame renders, HIP events around n back-to-back launches.
-usage: [RT_LIB_OVERRIDE=path/to/lib.so] time_one.py [--depth D] [--flags F] [--no-lights] [WORKLOAD ...]
+usage: [RT_LIB_OVERRIDE=path/to/lib.so] time_one.py [--depth D] [--flags F] [--no-lights] [--rows R] [WORKLOAD ...]
 (default: the headline workload; --depth / --flags / --no-lights vary the render: a ladder of
-such renders shows where a frame's time goes)"""
+such renders shows where a frame's time goes; --rows R renders only the lowest R image rows)"""
 import argparse
 import os
 import sys
@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--depth", type=int, default=0)
 ap.add_argument("--flags", type=int, default=0)
 ap.add_argument("--no-lights", action="store_true")
+ap.add_argument("--rows", type=int, default=0)
 ap.add_argument("workloads", nargs="*")
 args = ap.parse_args()
 
@@ -31,6 +32,8 @@ for name in (args.workloads or ["default_4k_d5"]):
         lights = lights[:0]
     p = abi.make_params(w, h, args.depth or d)
     p["flags"] = args.flags
+    if args.rows:
+        p["band_rows"], p["band_count"] = args.rows, 1
     n = 100 if name.startswith("default") else 4
     t.upload_scene(prims, lights)
     out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
@@ -52,5 +55,5 @@ for name in (args.workloads or ["default_4k_d5"]):
         ms = e0.elapsed_time(e1) / n
         best = min(best, ms)
         tot += ms
-    tag = f"{name} depth {args.depth or d} flags {args.flags}{' no lights' if args.no_lights else ''}"
+    tag = f"{name} depth {args.depth or d} flags {args.flags}{' no lights' if args.no_lights else ''}{f' rows {args.rows}' if args.rows else ''}"
     print(f"{os.path.basename(device.LIB_PATH)} {tag}: mean {tot / reps:.4f} best {best:.4f} ms/frame", flush=True)
