@@ -650,7 +650,7 @@ def main():
             "higher_is_better": True,
             "scaling": head["scaling"],
             "vs_baseline": None,
-            "dtype": "f64 decisions / f32 colour",
+            "dtype": "f64 decisions (f32 where the answer is certain at that precision) / f32 colour",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {width}x{height}, max_depth {depth}, {len(prims)} objects, "
@@ -662,6 +662,10 @@ def main():
                 "band_rows": strips.DEFAULT_BAND_ROWS,
                 "rays_counted": "the ray tree the image-only kernel walks: children under a material coefficient "
                                 "of zero (reflectivity 0 / transparency 0) contribute zero and are not traced",
+                "single_precision_paths": "shadow feelers of launches that use the anchor grids, and pixels whose "
+                                          "primary ray ends the ray tree, are answered in single precision where every "
+                                          "test is certain there (otherwise in double); their rays, tests and "
+                                          "flops are counted like the others'",
             },
             "roofline": roofline(prims, lights, depth, head["batched"], head["flops_per_launch"], head["kernel_ms"],
                                  head["fb_bytes"], args.workload, with_profile=(world == 1)),

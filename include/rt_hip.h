@@ -177,14 +177,17 @@ void rt_destroy(rt_ctx* ctx);
  * context's device current for the duration of the call and puts the caller's back.       */
 
 /*
- * Device memory a context holds besides the scene and the staging buffers of rt_render
- * (which grow to the largest frame rendered): renders with max_depth > 5 keep part of their
- * ray stacks in a workspace of 52.5 MiB (256 CUs), one per stream such a render was enqueued
- * on, allocated at the first such render on that stream; renders of scenes that use the
- * sphere tree (40 spheres or more) at smaller depths need 256 bytes per stream the same way.
- * Renders of smaller scenes at max_depth <= 5 allocate nothing.  rt_trim() waits for the
- * device to go idle and frees these workspaces (a later render allocates afresh); a caller
- * that creates streams freely calls it now and then.  No counterpart in the reference.
+ * Device memory a context holds besides the scene (with its derived tables: float images,
+ * sphere tree, anchor grids - about 5 MB for 1024 spheres) and the staging buffers of
+ * rt_render (which grow to the largest frame rendered): renders with max_depth > 5 keep part
+ * of their ray stacks in a workspace of 52.5 MiB (256 CUs), one per stream such a render was
+ * enqueued on, allocated and cleared at the first such render on that stream.  Renders at
+ * max_depth <= 5 allocate nothing, whatever the scene: those of scenes that use the sphere
+ * tree (40 spheres or more) need a 256-byte tile queue per stream, which comes out of a pool
+ * of 64 that rt_create allocates (a 65th stream allocates one).  No render enqueues a
+ * memset: a launch leaves its queue at zero.  rt_trim() waits for the device to go idle and
+ * frees the workspaces (a later render allocates afresh); a caller that creates streams
+ * freely calls it now and then.  No counterpart in the reference.
  */
 int rt_trim(rt_ctx* ctx);
 
@@ -214,6 +217,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims,
  * first, x ascending; image row 0 is the BOTTOM scanline as in the reference's
  * framebuffer (src/screen.h:62-64, bottom-up DIB src/screen.h:102-112).
  *   bgr        rows*width*3 bytes, B,G,R per pixel (src/screen.h:62-64)       required
+ *              Every hit, miss and spawn decision is the reference's; the colour
+ *              arithmetic (which decides nothing) runs in single precision where the
+ *              reference's runs in double: a channel is within 1 of the reference's
+ *              byte, and equal to it on more than 99.9 % of the pixels of a frame
  *   hit_id     rows*width int32: index of the object the primary ray hit
  *              (current_obj at src/main.cc:44, depth 1), -1 on a miss         nullable
  *   hit_mask   rows*width*rt_mask_words(max_depth) uint32. Nodes of the ray tree are
@@ -247,8 +254,10 @@ int rt_render_device(rt_ctx* ctx, const rt_params* p, void* stream, uint8_t* d_b
  * rt_render_device for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc): same arguments, same
  * results, but a render that needs a workspace (max_depth > 5, or a scene with the sphere
- * tree) keeps it in an array built into the library (52.5 MiB + 256 bytes per GPU the library runs on, held until the process
- * ends) instead of one allocated per stream, so the call never allocates or frees.  The
+ * tree) keeps it in an array built into the library (52.5 MiB + 256 bytes per GPU this entry
+ * point is used on, held until the process ends; the runtime loads the array's code object
+ * at the first call on a device, about 18 ms once) instead of one allocated per stream, so
+ * the call never allocates or frees.  The
  * array holds the stacks of the largest launch grid at max_depth 8, the library's limit;
  * a larger max_depth is refused with RT_ERR_ARG like everywhere else, and the frame size
  * does not matter.  All calls on one GPU share the array: two such renders that use the
@@ -306,7 +315,8 @@ int rt_debug_intersect(rt_ctx* ctx, const double* rays, int32_t n, int32_t prim,
  * Test hook: the nearest-hit loop of TraceRay (src/main.cc:37-47) on its own, run exactly
  * as the render kernel runs it, for n caller-supplied rays (6 doubles each: origin,
  * unit direction).  index_out: n int32, the object hit first (-1 = none); t_out: n doubles,
- * its t (0 when none).  flags: RT_FLAG_LINEAR / RT_FLAG_TREE, 0 = by scene size.
+ * its t (0 when none).  flags: RT_FLAG_LINEAR / RT_FLAG_TREE, RT_FLAG_NOGRID / RT_FLAG_GRID,
+ * 0 = by scene size.
  */
 int rt_debug_nearest(rt_ctx* ctx, const double* rays, int32_t n, uint32_t flags,
                      int32_t* index_out, double* t_out);
@@ -318,10 +328,13 @@ int rt_debug_nearest(rt_ctx* ctx, const double* rays, int32_t n, uint32_t flags,
  *   points      n * 3 doubles on the host
  *   light       index of the light the feelers aim at
  *   self        index of the object that is skipped (the shaded one), -1 = none
- *   flags       RT_FLAG_LINEAR / RT_FLAG_TREE as in rt_params.flags, 0 = by scene size
+ *   flags       RT_FLAG_LINEAR / RT_FLAG_TREE, RT_FLAG_NOGRID / RT_FLAG_GRID as in
+ *               rt_params.flags, 0 = by scene size
  *   first_out   n int32: index of the first occluder in container order, -1 = none
  *   factor_out  n doubles: its transmission factor (src/objects.h:40-46), 1.0 when none;
- *               colour arithmetic, evaluated in single precision on the device
+ *               colour arithmetic, evaluated in single precision on the device (with the
+ *               anchor grids, from the single-precision hit test where that is certain:
+ *               within 1.5e-3 of the reference's value)
  */
 int rt_debug_occluder(rt_ctx* ctx, const double* points, int32_t n, int32_t light, int32_t self,
                       uint32_t flags, int32_t* first_out, double* factor_out);
