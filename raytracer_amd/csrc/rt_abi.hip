@@ -206,9 +206,9 @@ bool use_tree(const rt_ctx* ctx, const rt_params* p) {
 // The anchor grids pay from a handful of spheres on (each feeler then tests the spheres of one
 // cell instead of all of them).
 constexpr int kGridMinSpheres = 8;
-// Scenes with at most this many spheres get the records of the primary-only pass (it tests every
-// sphere of the scene; launches with more spheres than kGridMinSpheres do not run it anyway
-// unless the caller switches the grids off).
+// Scenes with at most this many spheres and planes get the table of the pass that finishes
+// pixels ending at the primary ray (it tests every object of the scene; launches with more
+// spheres than kGridMinSpheres do not run it anyway unless the caller switches the grids off).
 constexpr size_t kFrontMaxSpheres = 16, kFrontMaxPlanes = 8;
 bool use_grid(const rt_ctx* ctx, const rt_params* p) {
     if (!ctx->d_grid_cells || (p->flags & RT_FLAG_NOGRID)) return false;
@@ -567,13 +567,13 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
             const double hd = s.p[0] * s.q[0] + s.p[1] * s.q[1] + s.p[2] * s.q[2];
             for (int c = 0; c < 3; ++c) {
                 fp.n[c] = static_cast<float>(mat[i].plane_normal[c]);
-                fp.n_lo[c] = static_cast<float>(s.q[c] - static_cast<double>(fp.n[c]));
+                fp.q[c] = s.q[c];
                 fp.kd[c] = mat[i].kd[c];
             }
             fp.ends = (mat[i].reflectivity == 0.0f && mat[i].transparency == 0.0f) ? 1.0f : 0.0f;
             fp.h = fgeom[i].v[4];
             fp.herr = fgeom[i].v[5];
-            fp.h_lo = static_cast<float>(hd - static_cast<double>(fp.h));
+            fp.hd = hd;
             fp.index = i;
             fp.transparency = static_cast<float>(s.transparency);
             fp.ambient = mat[i].ambient_intensity;

@@ -90,16 +90,18 @@ struct FrontPlane {
     float h, herr;           // as in FGeom: float(origin . normal), and its error bound
     int32_t index;           // position in the caller's object list
     float transparency;
-    float n_lo[3], h_lo;     // normal_ (double) - n and origin . normal_ (double) - h, rounded to float
+    double q[3];             // normal_ as TestCollision uses it (src/objects.h:93)
+    double hd;               // origin . normal_
     float kd[3];
     float ambient;
+    float pad[4];
 };
 struct FrontAnchor {
     double pos[3];           // the light (camera: zero)
     float ci[3];             // DLight::ci
     float pad[7];
 };
-constexpr int kFrontPlaneDwords = 16, kFrontAnchorDwords = 16;
+constexpr int kFrontPlaneDwords = 24, kFrontAnchorDwords = 16;
 static_assert(sizeof(FrontPlane) == 4 * kFrontPlaneDwords && sizeof(FrontAnchor) == 4 * kFrontAnchorDwords, "record size");
 
 // Per-lane stack entry: origin xyz, direction xyz, and one field that holds the path weight
@@ -107,7 +109,10 @@ static_assert(sizeof(FrontPlane) == 4 * kFrontPlaneDwords && sizeof(FrontAnchor)
 constexpr int kCounters = 10;  // fields of rt_counters
 static_assert(sizeof(rt_counters) == kCounters * sizeof(uint64_t), "rt_counters");
 constexpr int kStackFields = 7;
-constexpr int kWavesPerBlock = 4;
+#ifndef RT_WAVES_PER_BLOCK
+#define RT_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = RT_WAVES_PER_BLOCK;  // tiles (waves) per block
 constexpr int kTile = 8;  // a wave renders an 8x8 pixel tile
 
 struct KArgs {

@@ -1321,25 +1321,24 @@ __device__ __forceinline__ void store_pixel(AT& a, int x, int k, float cr, float
 //
 // The hit point.  For the un-normalised pixel vector v (src/view_frustum.h:37-46, exact in
 // double) and the plane (p0, n), h = p0.n: ip = v h / (v.n), the reference's o + d t for o = 0
-// up to rounding.  n and h come from the pass's own records as the sum of two floats (2^-48 of
-// their size off the doubles).  The pass only takes planes met at |cos| = |v.n| / |v| > 1e-3;
-// then v.n is within 6.8e-12 of itself (2^-48 sqrt(3) |v| from the records, 3 x 2^-53 |v|_1 from
-// the sums, over |v| 1e-3) and h within 3.9e-15 |p0|_1, so this ip lies within
-// 7e-12 (|ip| + |p0|_1) of the exact intersection, the reference's own within 1.2e-12 of it.
-// A feeler at distance dist >= 1e-3 (|ip|_1 + |p0|_1) from its light turns by less than 8.2e-9
-// for that, inside the slack of feel_ray()'s direction bound (its steps add up to
-// 5.5 x 2^-24 = 3.28e-7 of the 3.6e-7 allowed); the shift of the origin itself is added to the
-// bounds of the origin-dependent tests (en_ray, efront) as 1e-11 (|ip|_1 + |p0|_1).  |p0|_1 is
-// taken from the plane's record: herr = 1.01 U (|h| + |p0|_1).
+// up to rounding.  The pass only takes planes met at |cos| = |v.n| / |v| > 1e-3; then v.n is
+// within 5.8e-13 of itself (3 x 2^-53 |v|_1 from the sums, over |v| 1e-3) and h within
+// 3.4e-16 |p0|_1, so this ip lies within 6e-13 (|ip| + |p0|_1) of the exact intersection, and
+// so does the reference's own.  A feeler at distance dist >= 1e-3 (|ip|_1 + |p0|_1) from its
+// light turns by less than 1.2e-9 for that, inside the slack of feel_ray()'s direction bound
+// (its steps add up to 5.5 x 2^-24 = 3.28e-7 of the 3.6e-7 allowed); the shift of the origin
+// itself is added to the bounds of the origin-dependent tests (en_ray, efront) as
+// 1e-11 (|ip|_1 + |p0|_1).  |p0|_1 is taken from the plane's record:
+// herr = 1.01 U (|h| + |p0|_1).
 //
-// A wave of this pass is short, and what its time would consist of is the chain of scalar loads
-// it waits for one after the other (measured: 700 cycles each, 20 of them when the compiler
-// places them - it fetches every kernel argument and record where it is first used).  So the
-// pass fetches in three stages and holds the values in scalar registers from there on
-// (RT_HOLD): its arguments (the head of KArgs, FrontArgs) together with the tile's screen
-// bounds; the first plane and the camera's first two sphere records; per light its position,
-// colour and first two sphere records.  A scene with more planes or spheres adds a load per
-// further record.
+// A wave of this pass is short (about 900 issue cycles for a floor tile of the default scene),
+// so it should not spend its time on scalar loads that wait for one another: left to itself the
+// compiler fetches every kernel argument and record where it is first used, twenty waits in a
+// row.  The pass fetches in three stages instead and holds the values in scalar registers from
+// there on (RT_HOLD): its arguments (the head of KArgs, FrontArgs) together with the tile's
+// screen bounds; the first plane and the camera's first two sphere records; per light its
+// position, colour and first two sphere records.  A scene with more planes or spheres adds a
+// load per further record.
 #define RT_HOLD1(a) "+s"(a)
 #define RT_HOLD4(w, o) RT_HOLD1(w[o]), RT_HOLD1(w[o + 1]), RT_HOLD1(w[o + 2]), RT_HOLD1(w[o + 3])
 #define RT_HOLD8(w, o) RT_HOLD4(w, o), RT_HOLD4(w, o + 4)
@@ -1404,7 +1403,7 @@ __device__ __forceinline__ FRec as_frec(const FrontPlaneRec& r) {
     g.a0 = r.n0; g.a1 = r.n1; g.a2 = r.n2; g.r2 = -1.0f; g.b0 = r.h; g.b1 = r.herr;
     return g;
 }
-// The primary ray against the plane record in w[0..15].
+// The primary ray against the plane record in w[0..19].
 __device__ __forceinline__ void front_primary_plane(const uint32_t* w, const FeelRay& pr, V3 v, FrontState& s) {
     const FrontPlaneRec r = front_plane(w);
     bool hit;
@@ -1414,14 +1413,14 @@ __device__ __forceinline__ void front_primary_plane(const uint32_t* w, const Fee
     if (sure & hit) {
         s.cur = r.idx;
         s.ends = r.ends != 0.0f;
-        const V3 q = mk((double)r.n0 + (double)__uint_as_float(w[8]), (double)r.n1 + (double)__uint_as_float(w[9]),
-                        (double)r.n2 + (double)__uint_as_float(w[10]));
+        const V3 q = mk(__hiloint2double((int)w[9], (int)w[8]), __hiloint2double((int)w[11], (int)w[10]),
+                        __hiloint2double((int)w[13], (int)w[12]));
         s.vq = dot(v, q);
-        s.hd = (double)r.h + (double)__uint_as_float(w[11]);
+        s.hd = __hiloint2double((int)w[15], (int)w[14]);
         s.pb = r.herr * (1.0f / (1.01f * 6.0e-8f));
         s.nf = f3(r.n0, r.n1, r.n2);
-        s.kd = f3(__uint_as_float(w[12]), __uint_as_float(w[13]), __uint_as_float(w[14]));
-        s.amb = __uint_as_float(w[15]);
+        s.kd = f3(__uint_as_float(w[16]), __uint_as_float(w[17]), __uint_as_float(w[18]));
+        s.amb = __uint_as_float(w[19]);
     }
 }
 // The primary ray against the sphere record in w[0..3]: the line misses the sphere, or the
@@ -1469,11 +1468,11 @@ __device__ __forceinline__ bool primary_only_pixel(const FrontArgs& a, const int
     const cfdata_t anchors = planes + planes2 * kFrontPlaneDwords;
     const int anchor_stride = kFrontAnchorDwords + spheres2 * 8;
     const cfdata_t camera = anchors + (size_t)a.n_lights() * anchor_stride + kFrontAnchorDwords;
-    uint32_t p0[16], c0[4], c1[4];
+    uint32_t p0[20], c0[4], c1[4];
     front_load(p0, planes);  // (a scene without planes: whatever lies there, not looked at)
     front_load(c0, camera);
     front_load(c1, camera + 8);
-    __asm__ volatile("" : RT_HOLD8(p0, 0), RT_HOLD8(p0, 8), RT_HOLD4(c0, 0), RT_HOLD4(c1, 0));
+    __asm__ volatile("" : RT_HOLD8(p0, 0), RT_HOLD8(p0, 8), RT_HOLD4(p0, 16), RT_HOLD4(c0, 0), RT_HOLD4(c1, 0));
 
     // src/main.cc:135-138, src/view_frustum.h:37-46: frame row of strip row k, pixel vector
     const int band = (a.band_rows() == 1) ? k : (int)__umulhi((uint32_t)k, a.band_magic());
@@ -1501,7 +1500,7 @@ __device__ __forceinline__ bool primary_only_pixel(const FrontArgs& a, const int
     s.nf = f3(0.0f, 0.0f, 0.0f); s.kd = s.nf;
     if (n_planes > 0) front_primary_plane(p0, pr, v, s);
     for (int j = 1; j < n_planes; ++j) {
-        uint32_t pj[16];
+        uint32_t pj[20];
         front_load(pj, planes + j * kFrontPlaneDwords);
         front_primary_plane(pj, pr, v, s);
     }

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             }
             // pixels that end at the primary ray are finished in single precision (launches with
             // the container-order loops and the short stack; KArgs::front null = switched off)
-            if (!TREE && !DEEP && !GRID && fa.front() != nullptr) {
+            if (!TREE && !DEEP && !GRID && fa.front() != nullptr && fa.n_front() >= 0) {
                 have = have & !primary_only_pixel(fa, x, k, have);
                 if (!__any(have)) return;
             }
@@ -153,7 +153,7 @@ void whitted_batch_kernel(KBatch, int n) {
         const int x = tx * kTile + (lane & 7);
         const int k = ty * kTile + (lane >> 3);
         bool have = (x < a.width) && (k < a.rows);
-        if (!GRID && a.front != nullptr) {
+        if (!GRID && a.front != nullptr && a.n_front >= 0) {
             const RT_CONST uint32_t* kp = (const RT_CONST uint32_t*)&a;
             uint32_t unused;
             const FrontArgs fa = load_front_args(kp, kp, unused);
