@@ -74,7 +74,8 @@ struct rt_ctx {
     std::vector<rt_prim> host_prims;
     struct SkyEntry {
         rt_params p;
-        rt::SkyTable t;
+        rt::SkyTable t;        // in launch order (indexed by block row)
+        int32_t row_order = 0; // KArgs::row_order
     };
     std::vector<SkyEntry> sky_cache;
     size_t sky_next = 0;
@@ -696,23 +697,31 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims, const rt
 // tile of scenes small enough that working them out costs less than they save); null = none.
 constexpr int kSkyMaxPrims = 64;
 constexpr size_t kSkyCacheEntries = 16;
-static const rt::SkyTable* sky_bounds(rt_ctx* ctx, const rt_params* p, const rt::KArgs& a) {
+static const rt_ctx::SkyEntry* sky_bounds(rt_ctx* ctx, const rt_params* p, const rt::KArgs& a) {
     if (ctx->n_prims > kSkyMaxPrims || ctx->host_prims.empty()) return nullptr;
     for (const rt_ctx::SkyEntry& e : ctx->sky_cache)
         if (e.p.width == p->width && e.p.height == p->height && e.p.band_rows == p->band_rows &&
             e.p.band_first == p->band_first && e.p.band_step == p->band_step && e.p.band_count == p->band_count &&
             e.p.fov_deg == p->fov_deg)
-            return &e.t;
+            return &e;
     rt_ctx::SkyEntry e;
     e.p = *p;
-    rt::build_sky_table(ctx->host_prims.data(), ctx->n_prims, *p, a.rows, a.pw, a.ph, &e.t);
+    rt::SkyTable by_row;
+    uint32_t sphere_tiles[rt::kSkyRows];
+    rt::build_sky_table(ctx->host_prims.data(), ctx->n_prims, *p, a.rows, a.pw, a.ph, &by_row, sphere_tiles);
+    // the order of the launch's block rows, and the table laid out in that order
+    e.row_order = (a.tiles_y <= rt::kSkyRows) ? rt::tile_row_order(sphere_tiles, a.tiles_y) : 0;
+    if (const char* env = std::getenv("RT_ROW_ORDER")) e.row_order = std::atoi(env);  // measurement aid
+    e.t = by_row;
+    if (a.tiles_y <= rt::kSkyRows)
+        for (int b = 0; b < a.tiles_y; ++b) e.t.cols[b] = by_row.cols[rt::tile_row_of_block(e.row_order, b, a.tiles_y)];
     if (ctx->sky_cache.size() < kSkyCacheEntries) {
         ctx->sky_cache.push_back(e);
-        return &ctx->sky_cache.back().t;
+        return &ctx->sky_cache.back();
     }
     ctx->sky_next = (ctx->sky_next + 1) % kSkyCacheEntries;
     ctx->sky_cache[ctx->sky_next] = e;
-    return &ctx->sky_cache[ctx->sky_next].t;
+    return &ctx->sky_cache[ctx->sky_next];
 }
 
 // Enqueue one render with device outputs on `stream`; the deep-stack workspace is `ws` when
@@ -740,8 +749,12 @@ static int enqueue_render(rt_ctx* ctx, const rt_params* p, hipStream_t stream, v
             return rc;
     }
     const rt::SkyTable* sky = nullptr;
-    if (!emit && !count && !tree && rt::stack_global_entries(a.max_depth) == 0 && !(p->flags & RT_FLAG_NOSKY))
-        sky = sky_bounds(ctx, p, a);
+    if (!emit && !count && !tree && rt::stack_global_entries(a.max_depth) == 0 && !(p->flags & RT_FLAG_NOSKY)) {
+        if (const rt_ctx::SkyEntry* e = sky_bounds(ctx, p, a)) {
+            sky = &e->t;
+            a.row_order = e->row_order;
+        }
+    }
     RT_HIP_TRY(ctx, rt::launch_whitted(a, emit, count, tree, use_grid(ctx, p), deep_blocks, stream, sky));
     return RT_OK;
 }
@@ -809,6 +822,9 @@ int rt_render_device_batch(rt_ctx* const* ctxs, const rt_params* params, int32_t
             }
             if (a.tiles_x <= 0 || a.tiles_y <= 0) continue;  // an empty partition
             a.bgr = d_bgr[base + i];
+            // launches with one wave per tile: the rows with the long ray trees first
+            if (!tree && !(params[base + i].flags & RT_FLAG_NOSKY))
+                if (const rt_ctx::SkyEntry* e = sky_bounds(ctxs[base + i], &params[base + i], a)) a.row_order = e->row_order;
             tiles += static_cast<long long>(a.tiles_x) * a.tiles_y;
             if (tiles > INT32_MAX) return fail(first, RT_ERR_ARG, "rt_render_device_batch: too many tiles in one launch");
             b.a[live] = a;

@@ -62,14 +62,46 @@ inline int sky_unit_shift(int width) {
     return s;
 }
 
-// Fills `out` for the strip `p` describes (rows = rt_strip_rows(p), pixel pitch pw x ph).  A strip
-// of more than kSkyRows tile rows gets the table that leaves every tile in.
+// The order in which a launch with one wave per tile goes through its rows of tiles
+// (KArgs::row_order): block row b renders tile row (first + b) mod tiles_y, or (first - b) mod
+// tiles_y with bit 30 set.  A wave on a sphere walks a ray tree, a wave on a plane or on the sky
+// is short; a launch whose last blocks are long waves ends with most of the chip idle, so the
+// rows that hold spheres go first and the launch ends on short waves.  `sphere_tiles[ty]` = how
+// many tiles of row ty some sphere's bounds cover.  The rows with spheres form a band [lo, hi]
+// of the strip (interleaved strips: of its rows); the launch starts at the end of the band that
+// has the shorter rest behind it and runs through the band, then through the longer rest, so
+// that as many short waves as possible are still to come when the last long ones start.
+inline int32_t tile_row_order(const uint32_t* sphere_tiles, int tiles_y) {
+    int lo = -1, hi = -1;
+    for (int ty = 0; ty < tiles_y; ++ty)
+        if (sphere_tiles[ty] > 0) {
+            if (lo < 0) lo = ty;
+            hi = ty;
+        }
+    if (lo < 0 || tiles_y > 0xffff) return 0;
+    const int below = lo, above = tiles_y - 1 - hi;
+    // upwards from lo: band, rows above, rows below last; downwards from hi: band, below, above last
+    return (below >= above) ? lo : (hi | 0x40000000);
+}
+inline int tile_row_of_block(int32_t order, int b, int tiles_y) {
+    int ty = (order & 0x40000000) ? (order & 0xffff) - b : (order & 0xffff) + b;
+    if (ty < 0) ty += tiles_y;
+    if (ty >= tiles_y) ty -= tiles_y;
+    return ty;
+}
+
+// Fills `out` for the strip `p` describes (rows = rt_strip_rows(p), pixel pitch pw x ph), indexed
+// by tile row, and - when asked - `sphere_tiles[ty]` (kSkyRows entries) with the number of tiles
+// of row ty inside some sphere's bounds.  A strip of more than kSkyRows tile rows gets the table
+// that leaves every tile in.
 inline void build_sky_table(const rt_prim* prims, int n_prims, const rt_params& p, int rows, double pw, double ph,
-                            SkyTable* out) {
+                            SkyTable* out, uint32_t* sphere_tiles = nullptr) {
     using namespace detail;
     const int tiles_y = (rows + kTile - 1) / kTile;
     const int shift = sky_unit_shift(p.width);
     for (int e = 0; e < kSkyRows; ++e) out->cols[e] = 0xff00u;  // lo = 0, hi = 255: every column
+    if (sphere_tiles)
+        for (int e = 0; e < kSkyRows; ++e) sphere_tiles[e] = 0;
     if (tiles_y > kSkyRows) return;
     for (int ty = 0; ty < tiles_y; ++ty) {
         out->cols[ty] = 0x0001u;  // lo = 1, hi = 0: none
@@ -78,7 +110,8 @@ inline void build_sky_table(const rt_prim* prims, int n_prims, const rt_params& 
         const double ya = (static_cast<double>(strip_to_frame_row(p, k0) - p.height / 2) + 0.5 - 1.0) * ph;
         const double yb = (static_cast<double>(strip_to_frame_row(p, k1) - p.height / 2) + 0.5 + 1.0) * ph;
         double xlo = INFINITY, xhi = -INFINITY;  // union of the objects' X ranges over this tile row
-        for (int i = 0; i < n_prims && !(xlo == -INFINITY && xhi == INFINITY); ++i) {
+        // (once the row is covered from end to end only the spheres' shares are still of interest)
+        for (int i = 0; i < n_prims && (sphere_tiles || !(xlo == -INFINITY && xhi == INFINITY)); ++i) {
             const rt_prim& s = prims[i];
             double lo = -INFINITY, hi = INFINITY;
             if (s.type == RT_PRIM_SPHERE) {
@@ -88,6 +121,11 @@ inline void build_sky_table(const rt_prim* prims, int n_prims, const rt_params& 
                 if (!forward_slope_range(s.p[2], s.p[1], rg, &vlo, &vhi)) continue;
                 if (vhi < ya || vlo > yb) continue;
                 if (!forward_slope_range(s.p[2], s.p[0], rg, &lo, &hi)) continue;
+                if (sphere_tiles) {  // its share of this row, in tiles
+                    const double half = static_cast<double>(p.width / 2);
+                    const double a = std::max(0.0, lo / pw + half), b = std::min(static_cast<double>(p.width), hi / pw + half);
+                    if (b > a) sphere_tiles[ty] += static_cast<uint32_t>((b - a) / kTile) + 1u;
+                }
             } else {
                 // hit only where sg (X n_x + Y n_y + n_z) > 0, sg = sign(p . n); an uncertain sign of
                 // p . n leaves the whole row in

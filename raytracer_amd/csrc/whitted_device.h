@@ -132,8 +132,11 @@ struct KArgs {
     float scene_p1max;         // >= |centre|_1 of every sphere (filter bound)
     int32_t sky_unit_shift;    // see SkyTable
     float bgr_c[3];            // background colour
-    int32_t max_depth;
+    int32_t row_order;         // launches with one wave per tile: block row b renders tile row
+                               // (first + b) mod tiles_y, or (first - b) mod tiles_y when bit 30 is set;
+                               // first = the low 16 bits (see tile_row_order() in sky_table.h)
     // ---- the rest
+    int32_t max_depth;
     const DGeom* geom;
     const DMat* mat;
     const DLight* lights;
@@ -169,7 +172,7 @@ struct KArgs {
 constexpr int kFrontArgDwords = 24;
 static_assert(offsetof(KArgs, front) == 0 && offsetof(KArgs, bgr) == 8 && offsetof(KArgs, pw) == 16 &&
                   offsetof(KArgs, n_planes) == 32 && offsetof(KArgs, band_magic) == 68 && offsetof(KArgs, bgr_c) == 80 &&
-                  offsetof(KArgs, max_depth) == 92 && offsetof(KArgs, geom) == 4 * kFrontArgDwords,
+                  offsetof(KArgs, row_order) == 92 && offsetof(KArgs, max_depth) == 4 * kFrontArgDwords,
               "FrontArgs reads the head of KArgs by position");
 
 // Screen bounds of the scene for launches with one wave per tile (sky_table.h): tile row ty reads

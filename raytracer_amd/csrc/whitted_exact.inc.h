@@ -1363,6 +1363,7 @@ struct FrontArgs {
     __device__ __forceinline__ float scene_p1max() const { return __uint_as_float(w[18]); }
     __device__ __forceinline__ int sky_unit_shift() const { return (int)w[19]; }
     __device__ __forceinline__ float bgr_c(int i) const { return __uint_as_float(w[20 + i]); }
+    __device__ __forceinline__ uint32_t row_order() const { return w[23]; }
 };
 // Fetches the arguments at `kp` (a KArgs in the constant address space) and the word at `extra`
 // with loads that are issued together.

@@ -67,18 +67,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         trace_queue<MW, COUNT, TREE, DEEP, LATE, GRID>(feed, stk, gstk, lane, cnt);
     } else {
         const int tx = blockIdx.x * kWavesPerBlock + wave;  // a block = 4 tiles side by side
-        const int ty = blockIdx.y;
-        const int x = tx * kTile + (lane & 7);
-        const int k = ty * kTile + (lane >> 3);  // row in strip order
+        int ty = blockIdx.y;
+        int x = tx * kTile + (lane & 7);
+        int k = ty * kTile + (lane >> 3);  // row in strip order
         bool have;
         if (MW == 0 && !COUNT) {
             // a tile outside the screen bounds of the scene is background (src/main.cc:49-53)
             const RT_CONST uint32_t* kp = (const RT_CONST uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
             const RT_CONST uint32_t* sky = (const RT_CONST uint32_t*)((const RT_CONST char*)kp + sizeof(KArgs));
-            const uint32_t row = min((uint32_t)ty, (uint32_t)(kSkyRows - 1));
+            // (the table is indexed by the block row: the host has laid it out in launch order)
+            const uint32_t row = min((uint32_t)blockIdx.y, (uint32_t)(kSkyRows - 1));
             uint32_t word;
             // (the arguments the rest of this branch needs, and the bounds, in one fetch)
             const FrontArgs fa = load_front_args(kp, sky + (row >> 1), word);
+            // The rows of tiles are launched in the order the host chose: those that hold the long
+            // ray trees first, so that the launch ends on short waves (KArgs::row_order)
+            const uint32_t order = fa.row_order();
+            ty = (order & 0x40000000u) ? (int)(order & 0xffffu) - ty : (int)(order & 0xffffu) + ty;
+            ty += (ty < 0) ? (int)gridDim.y : 0;
+            ty -= (ty >= (int)gridDim.y) ? (int)gridDim.y : 0;
+            k = ty * kTile + (lane >> 3);
             const uint32_t rng = word >> ((row & 1u) << 4);
             const uint32_t col = (uint32_t)tx >> fa.sky_unit_shift();
             have = (x < fa.width()) && (k < fa.rows());
@@ -149,7 +157,11 @@ void whitted_batch_kernel(KBatch, int n) {
         if ((int)blockIdx.y >= a.tiles_y || (int)(blockIdx.x * kWavesPerBlock) >= a.tiles_x) return;
         double* stk = lds_stack + (size_t)wave * tile_stack_lds_entries(a.max_depth) * kStackFields * 64 + lane;
         const int tx = blockIdx.x * kWavesPerBlock + wave;
-        const int ty = blockIdx.y;
+        // (the render's rows of tiles in the order its host chose, KArgs::row_order)
+        const uint32_t order = (uint32_t)a.row_order;
+        int ty = (order & 0x40000000u) ? (int)(order & 0xffffu) - (int)blockIdx.y : (int)(order & 0xffffu) + (int)blockIdx.y;
+        ty += (ty < 0) ? a.tiles_y : 0;
+        ty -= (ty >= a.tiles_y) ? a.tiles_y : 0;
         const int x = tx * kTile + (lane & 7);
         const int k = ty * kTile + (lane >> 3);
         bool have = (x < a.width) && (k < a.rows);
