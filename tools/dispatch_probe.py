@@ -1,5 +1,5 @@
 """How fast the chip gets through waves that do next to nothing: a 4K frame of the default scene
-turned away from the camera (every primary ray misses), rendered (a) with the screen bounds - a
+moved behind the camera (every primary ray misses), rendered (a) with the screen bounds - a
 wave stores the background and ends, (b) without them but with the single-precision pass - a wave
 classifies its primary rays, (c) with neither - a wave normalises its rays in double and searches
 the scene.  usage: python tools/dispatch_probe.py"""
@@ -16,7 +16,11 @@ from raytracer_amd.device import DeviceTracer  # noqa: E402
 t = DeviceTracer(0)
 prims, lights = scenes.default_scene()
 prims = prims.copy()
-prims["p"] = prims["p"] * np.array([1.0, 1.0, -1.0])
+pp, qq = prims["p"].copy(), prims["q"].copy()
+pp[:, 2] -= 1000.0           # the spheres far behind the camera
+pp[0] = (0.0, 0.0, -1000.0)  # the floor: a plane behind the camera, facing it
+qq[0] = (0.0, 0.0, 1.0)
+prims["p"], prims["q"] = pp, qq
 t.upload_scene(prims, lights)
 w, h = 3840, 2160
 out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")

@@ -31,7 +31,7 @@ if SCENE == "glass":
 else:
     LADDER = ["background", "depth2_dark", "depth2", "depth3", "depth4", "depth5"]
     N = 5
-    KERNEL = "whitted_kernel<0, false, false, false, false>"
+    KERNEL = "whitted_kernel<0, false, false, false, false, false>"
 W, H = 3840, 2160
 
 
