@@ -102,6 +102,11 @@ typedef struct rt_light {
                                  partition) which 8x8 tiles no primary ray can hit anything
                                  in, and those tiles get the background colour
                                  (src/main.cc:49-53) untraced; the image is the same.     */
+#define RT_DEBUG_RECORDS 256u  /* rt_debug_nearest / rt_debug_occluder only: run the search the
+                                 way the single-precision pass below runs it (small scenes:
+                                 every object's record, tested in single precision); an index
+                                 of -2 = that search is not certain for this ray, which the
+                                 render kernels then walk in double precision               */
 #define RT_FLAG_NOFRONT 128u  /* walk every pixel in double precision.  Without it an
                                  image-only render of a small scene (depth <= 5) finishes the
                                  pixels whose primary ray ends its ray tree - it misses
@@ -316,7 +321,10 @@ int rt_debug_intersect(rt_ctx* ctx, const double* rays, int32_t n, int32_t prim,
  * as the render kernel runs it, for n caller-supplied rays (6 doubles each: origin,
  * unit direction).  index_out: n int32, the object hit first (-1 = none); t_out: n doubles,
  * its t (0 when none).  flags: RT_FLAG_LINEAR / RT_FLAG_TREE, RT_FLAG_NOGRID / RT_FLAG_GRID,
- * 0 = by scene size.
+ * 0 = by scene size.  With RT_DEBUG_RECORDS (rays from the origin only, small scenes): the
+ * search of the single-precision pass: the one plane it is certain the ray hits first (a plane
+ * only when nothing else can be hit), -1 = certainly nothing, -2 = not certain; t_out is then
+ * only accurate to rounding.  RT_ERR_STATE when the scene has no records (too large).
  */
 int rt_debug_nearest(rt_ctx* ctx, const double* rays, int32_t n, uint32_t flags,
                      int32_t* index_out, double* t_out);
@@ -329,7 +337,8 @@ int rt_debug_nearest(rt_ctx* ctx, const double* rays, int32_t n, uint32_t flags,
  *   light       index of the light the feelers aim at
  *   self        index of the object that is skipped (the shaded one), -1 = none
  *   flags       RT_FLAG_LINEAR / RT_FLAG_TREE, RT_FLAG_NOGRID / RT_FLAG_GRID as in
- *               rt_params.flags, 0 = by scene size
+ *               rt_params.flags, 0 = by scene size; RT_DEBUG_RECORDS: the search of the
+ *               single-precision pass (first_out -2 = not certain)
  *   first_out   n int32: index of the first occluder in container order, -1 = none
  *   factor_out  n doubles: its transmission factor (src/objects.h:40-46), 1.0 when none;
  *               colour arithmetic, evaluated in single precision on the device (with the

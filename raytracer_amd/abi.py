@@ -27,6 +27,7 @@ RT_FLAG_NOGRID = 16
 RT_FLAG_GRID = 32
 RT_FLAG_NOSKY = 64
 RT_FLAG_NOFRONT = 128
+RT_DEBUG_RECORDS = 256
 
 PRIM_DTYPE = np.dtype(
     [

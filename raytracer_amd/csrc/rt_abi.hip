@@ -1109,6 +1109,12 @@ int rt_debug_nearest(rt_ctx* ctx, const double* rays, int32_t n, uint32_t flags,
     if ((rc = reserve(ctx, ctx->dbg_t, N * 8)) != RT_OK) return rc;
     if ((rc = reserve(ctx, ctx->dbg_unit, N * 4)) != RT_OK) return rc;
     RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->dbg_in.ptr, rays, N * 48, hipMemcpyHostToDevice, ctx->stream));
+    if (flags & RT_DEBUG_RECORDS) {
+        if (!a.front) return fail(ctx, RT_ERR_STATE, "rt_debug_nearest: the scene has no records for the single-precision pass");
+        RT_HIP_TRY(ctx, rt::launch_debug_records(a, false, 0, -1, static_cast<const double*>(ctx->dbg_in.ptr), n,
+                                                 static_cast<int32_t*>(ctx->dbg_unit.ptr), static_cast<double*>(ctx->dbg_t.ptr),
+                                                 ctx->stream));
+    } else
     RT_HIP_TRY(ctx, rt::launch_debug_nearest(a, use_tree(ctx, &p), use_grid(ctx, &p), static_cast<const double*>(ctx->dbg_in.ptr), n,
                                              static_cast<int32_t*>(ctx->dbg_unit.ptr),
                                              static_cast<double*>(ctx->dbg_t.ptr), ctx->stream));
@@ -1137,6 +1143,12 @@ int rt_debug_occluder(rt_ctx* ctx, const double* points, int32_t n, int32_t ligh
     if ((rc = reserve(ctx, ctx->dbg_t, N * 8)) != RT_OK) return rc;
     if ((rc = reserve(ctx, ctx->dbg_unit, N * 4)) != RT_OK) return rc;
     RT_HIP_TRY(ctx, hipMemcpyAsync(ctx->dbg_in.ptr, points, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    if (flags & RT_DEBUG_RECORDS) {
+        if (!a.front) return fail(ctx, RT_ERR_STATE, "rt_debug_occluder: the scene has no records for the single-precision pass");
+        RT_HIP_TRY(ctx, rt::launch_debug_records(a, true, light, self, static_cast<const double*>(ctx->dbg_in.ptr), n,
+                                                 static_cast<int32_t*>(ctx->dbg_unit.ptr), static_cast<double*>(ctx->dbg_t.ptr),
+                                                 ctx->stream));
+    } else
     RT_HIP_TRY(ctx, rt::launch_debug_occluder(a, use_tree(ctx, &p), use_grid(ctx, &p), light, self,
                                               static_cast<const double*>(ctx->dbg_in.ptr), n,
                                               static_cast<int32_t*>(ctx->dbg_unit.ptr),

@@ -277,6 +277,11 @@ hipError_t launch_whitted(const KArgs& a, bool emit, bool count, bool tree, bool
 
 
 // Enqueue the nearest-hit hook (rt_debug_nearest); only the scene fields of `a` are read.
+// The record-based single-precision searches of primary_only_pixel() on their own (test hook):
+// occluder = the feeler search from n points towards `light`, else the primary search along n rays
+// from the origin; index_out -2 = not certain.
+hipError_t launch_debug_records(const KArgs& a, bool occluder, int light, int self, const double* in, int n, int32_t* index_out,
+                                double* value_out, hipStream_t stream);
 hipError_t launch_debug_nearest(const KArgs& a, bool tree, bool grid, const double* rays, int n, int32_t* index_out, double* t_out,
                                 hipStream_t stream);
 

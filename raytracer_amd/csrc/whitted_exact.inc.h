@@ -1431,7 +1431,7 @@ __device__ __forceinline__ void front_primary_sphere(const uint32_t* w, const Fe
     ok = ok & ((__builtin_fmaf(-t, t, __uint_as_float(w[3])) > pr.eray) | (t < -pr.efront));
 }
 // A shadow feeler against the plane record in w[0..7] / the sphere record in w[0..7], to be
-// called in container order.
+// called in container order; `cur` = the object the feeler starts on, which is skipped.
 __device__ __forceinline__ void front_feeler_plane(const uint32_t* w, const FeelRay& fr, int cur, bool& good, int& best, float& occl) {
     const FrontPlaneRec r = front_plane(w);
     if (good & (r.idx != cur) & (r.idx < best)) {
@@ -1441,12 +1441,12 @@ __device__ __forceinline__ void front_feeler_plane(const uint32_t* w, const Feel
         if (good & hit) { best = r.idx; occl = factor; }
     }
 }
-__device__ __forceinline__ void front_feeler_sphere(const uint32_t* w, const FeelRay& fr, bool& good, int& best, float& occl) {
+__device__ __forceinline__ void front_feeler_sphere(const uint32_t* w, const FeelRay& fr, int cur, bool& good, int& best, float& occl) {
     LRec l;
     l.x = __uint_as_float(w[0]); l.y = __uint_as_float(w[1]); l.z = __uint_as_float(w[2]); l.thr = __uint_as_float(w[3]);
     const int idx = (int)w[4];
     const float t = __builtin_fmaf(l.z, fr.d.z, __builtin_fmaf(l.y, fr.d.y, l.x * fr.d.x));
-    if (good & (idx < best) & !(__builtin_fmaf(-t, t, l.thr) > fr.eray)) {
+    if (good & (idx != cur) & (idx < best) & !(__builtin_fmaf(-t, t, l.thr) > fr.eray)) {
         bool hit;
         float factor = 0.0f;
         good = classify_sphere(l, t, __uint_as_float(w[5]), __uint_as_float(w[6]), __uint_as_float(w[7]), fr, hit, factor);
@@ -1546,12 +1546,12 @@ __device__ __forceinline__ bool primary_only_pixel(const FrontArgs& a, const int
                 front_load(pj, planes + j * kFrontPlaneDwords);
                 front_feeler_plane(pj, fr, s.cur, good, best, occl);
             }
-            front_feeler_sphere(e0, fr, good, best, occl);
-            front_feeler_sphere(e1, fr, good, best, occl);
+            front_feeler_sphere(e0, fr, s.cur, good, best, occl);
+            front_feeler_sphere(e1, fr, s.cur, good, best, occl);
             for (int j = 2; j < spheres2; ++j) {
                 uint32_t ej[8];
                 front_load(ej, anchor + kFrontAnchorDwords + j * 8);
-                front_feeler_sphere(ej, fr, good, best, occl);
+                front_feeler_sphere(ej, fr, s.cur, good, best, occl);
             }
             // src/objects.h:50-60, the operations of the walk's shading in the same order
             const float dk = __builtin_fabsf(dotf(s.nf, fr.d)) * occl;

@@ -331,6 +331,80 @@ __global__ void debug_nearest_kernel(KArgs a, const double* rays, int n, int32_t
     t_out[i] = (cur >= 0) ? nearest : 0.0;
 }
 
+// rt_debug_nearest / rt_debug_occluder with RT_DEBUG_RECORDS: the single-precision searches of
+// primary_only_pixel() on their own, one lane per ray / point, over the same records with the
+// same per-record tests.  -2 = not certain at that precision (the render kernel then walks the
+// pixel in double).
+__global__ void debug_records_nearest_kernel(KArgs a, const double* rays, int n, int32_t* index_out, double* t_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float U = 6.0e-8f;
+    const cfdata_t planes = (cfdata_t)(const float*)a.front;
+    const int n_planes = a.n_planes, n_spheres = a.n_front;
+    const int planes2 = (n_planes + 1) & ~1, spheres2 = n_spheres > 0 ? ((n_spheres + 1) & ~1) : 2;
+    const cfdata_t camera = planes + planes2 * kFrontPlaneDwords + (size_t)a.n_lights * (kFrontAnchorDwords + spheres2 * 8) + kFrontAnchorDwords;
+    const V3 d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);  // a unit vector from the origin
+    FeelRay pr;
+    pr.o = f3(0.0f, 0.0f, 0.0f);
+    pr.d = f3((float)d.x, (float)d.y, (float)d.z);
+    pr.dist = 0.0f;
+    pr.en_ray = 0.0f;
+    pr.eray = 1.0e-13f * a.scene_p1max * a.scene_p1max;
+    pr.efront = 16.0f * U * a.scene_p1max;
+    pr.valid = true;
+    FrontState s;
+    s.ok = true; s.cur = -1; s.ends = false; s.vq = 1.0; s.hd = 0.0; s.pb = 0.0f; s.amb = 0.0f;
+    s.nf = f3(0.0f, 0.0f, 0.0f); s.kd = s.nf;
+    for (int j = 0; j < n_planes; ++j) {
+        uint32_t pj[20];
+        front_load(pj, planes + j * kFrontPlaneDwords);
+        front_primary_plane(pj, pr, d, s);
+    }
+    for (int j = 0; j < spheres2; ++j) {
+        uint32_t cj[4];
+        front_load(cj, camera + j * 8);
+        front_primary_sphere(cj, pr, s.ok);
+    }
+    index_out[i] = s.ok ? s.cur : -2;
+    t_out[i] = (s.ok && s.cur >= 0) ? s.hd / s.vq : 0.0;  // (p0.n) / (d.n): the hit parameter up to rounding
+}
+__global__ void debug_records_occluder_kernel(KArgs a, int light, int self, const double* points, int n, int32_t* first_out,
+                                              double* factor_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const cfdata_t planes = (cfdata_t)(const float*)a.front;
+    const int n_planes = a.n_planes, n_spheres = a.n_front;
+    const int planes2 = (n_planes + 1) & ~1, spheres2 = n_spheres > 0 ? ((n_spheres + 1) & ~1) : 2;
+    const cfdata_t anchor = planes + planes2 * kFrontPlaneDwords + (size_t)light * (kFrontAnchorDwords + spheres2 * 8);
+    const RT_CONST double* lp = (const RT_CONST double*)anchor;
+    const V3 ip = mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
+    const FeelRay fr = feel_ray(ip, mk(lp[0], lp[1], lp[2]) - ip, a.scene_p1max);
+    bool good = fr.valid;
+    int best = 0x7fffffff;
+    float occl = 1.0f;
+    for (int j = 0; j < n_planes; ++j) {
+        uint32_t pj[8];
+        front_load(pj, planes + j * kFrontPlaneDwords);
+        front_feeler_plane(pj, fr, self, good, best, occl);
+    }
+    for (int j = 0; j < spheres2; ++j) {
+        uint32_t ej[8];
+        front_load(ej, anchor + kFrontAnchorDwords + j * 8);
+        front_feeler_sphere(ej, fr, self, good, best, occl);
+    }
+    first_out[i] = good ? ((best != 0x7fffffff) ? best : -1) : -2;
+    factor_out[i] = (good && best != 0x7fffffff) ? occl : 1.0;
+}
+hipError_t launch_debug_records(const KArgs& a, bool occluder, int light, int self, const double* in, int n, int32_t* index_out,
+                                double* value_out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if (!a.front) return hipErrorInvalidValue;
+    const dim3 g((n + 255) / 256), block(256);
+    if (occluder) hipLaunchKernelGGL(debug_records_occluder_kernel, g, block, 0, stream, a, light, self, in, n, index_out, value_out);
+    else hipLaunchKernelGGL(debug_records_nearest_kernel, g, block, 0, stream, a, in, n, index_out, value_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_debug_nearest(const KArgs& a, bool tree, bool grid, const double* rays, int n, int32_t* index_out,
                                 double* t_out, hipStream_t stream) {
     if (n <= 0) return hipSuccess;

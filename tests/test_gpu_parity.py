@@ -497,6 +497,67 @@ def test_shadow_feeler_grazing(tracer, name):
         assert (f_o >= 0).any() and (f_o < 0).any()
 
 
+@pytest.mark.parametrize("name", ["default", "glass6", "contacts"])
+def test_single_precision_record_searches(tracer, name):
+    """The searches of the pass that finishes pixels ending at the primary ray, on their own
+    (RT_DEBUG_RECORDS): wherever they say they are certain their answer is the checker's - the
+    first occluder of a feeler (points whose feelers graze spheres within a relative 1e-16..1e-3,
+    points on and next to the floor, random points), and what a ray from the camera hits first
+    (rays grazing the spheres, rays along and across the planes) - and they are certain for all
+    but a small share of ordinary rays."""
+    matte = dict(reflectivity=0.0, transparency=0.0)
+    if name == "default":
+        prims, lights = scenes.default_scene()
+    elif name == "glass6":
+        prims, lights = scenes.glass_scene(n_spheres=6, n_lights=3)
+    else:
+        prims = scenes._stack([
+            scenes.plane((0, -3, 0), (0, 1, 0), (0.6, 0.6, 0.6), **matte),
+            scenes.plane((0, 0, 40), (0.3, 0.2, -1), (0.8, 0.4, 0.3), **matte),
+            scenes.sphere((-4, -2, 12), 1.0, (1, 1, 1), reflectivity=0.2, transparency=0.8, refraction_index=1.4),
+            scenes.sphere((0, -3, 14), 1.5, (0.9, 0.2, 0.2), **matte),
+            scenes.sphere((4, -1.999999, 10), 1.0, (0.2, 0.9, 0.2), reflectivity=0.6),
+        ], abi.PRIM_DTYPE)
+        lights = scenes._stack([scenes.point_light((1, 1, 1), 0.6, (0, 8, 10)), scenes.point_light((1, 0.9, 0.8), 0.3, (-6, 2, 2)),
+                                scenes.point_light((1, 1, 1), 0.4, (2.0001, -1, 12))], abi.LIGHT_DTYPE)
+    tracer.upload_scene(prims, lights)
+    rng = np.random.default_rng(4242)
+    planes = [i for i, pr in enumerate(prims) if pr["type"] == abi.RT_PRIM_PLANE]
+    sure = total = 0
+    for light in range(min(len(lights), 3)):
+        pts = _grazing_points(prims, lights, light, rng, per_sphere=400)
+        floor = np.stack([rng.uniform(-20, 20, 4000), np.full(4000, -3.0) + rng.choice([0.0, 1e-12, -1e-12, 1e-6], 4000),
+                          rng.uniform(2, 60, 4000)], 1)
+        pts = np.concatenate([pts, floor, rng.uniform(-8, 8, (2000, 3)) + np.array([0.0, 2.0, 14.0])])
+        for self_index in [-1] + planes[:1]:
+            f_o, k_o = oracle_lib.occluder(prims, lights, light, self_index, pts)
+            f_d, k_d = tracer.debug_occluder(pts, light, self_index, abi.RT_DEBUG_RECORDS)
+            certain = f_d != -2
+            bad = np.nonzero(certain & (f_d != f_o))[0]
+            assert bad.size == 0, f"{name} light {light} self {self_index}: {bad[:5]} {f_d[bad[:5]]} {f_o[bad[:5]]}"
+            assert np.allclose(k_d[certain], k_o[certain], rtol=2e-5, atol=1.5e-3), float(np.abs(k_d - k_o)[certain].max())
+            if self_index >= 0:  # feelers that start on the floor with the floor skipped, and random points
+                sure += int(certain[-6000:].sum())
+                total += 6000
+    assert sure > 0.97 * total, (sure, total)
+    # primary rays: all from the camera
+    rays = _grazing_rays(prims, rng, per_sphere=600, origin=(0.0, 0.0, 0.0))
+    m = 6000
+    d = np.stack([rng.uniform(-0.7, 0.7, m), rng.uniform(-0.4, 0.4, m) * rng.choice([1.0, 1e-3, 1e-6], m), np.ones(m)], 1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([rays, np.concatenate([np.zeros((m, 3)), d], axis=1)])
+    i_o, t_o = oracle_lib.nearest(prims, rays)
+    i_d, t_d = tracer.debug_nearest(rays, abi.RT_DEBUG_RECORDS)
+    certain = i_d != -2
+    bad = np.nonzero(certain & (i_d != i_o))[0]
+    assert bad.size == 0, f"{name}: {bad[:5]} {i_d[bad[:5]]} {i_o[bad[:5]]}"
+    hit = certain & (i_d >= 0)
+    assert np.all(np.isin(i_d[hit], planes))  # it only ever names a plane
+    assert np.allclose(t_d[hit], t_o[hit], rtol=1e-9)
+    # (with two planes in view most rays hit both: which is nearer is left to the walk)
+    assert certain[-m:].mean() > (0.2 if name == "contacts" else 0.5) and (i_d == -1).any()
+
+
 def _grazing_rays(prims, rng, per_sphere=300, origin=None):
     """Unit rays from random origins (or all from `origin`) that pass a sphere's silhouette
     within a relative 1e-16 .. 1e-3, half of them pointing away from it, plus rays grazing the
