@@ -224,6 +224,19 @@ __host__ __device__ inline int tile_stack_lds_entries(int max_depth) {
 inline size_t tile_stack_lds_bytes(int max_depth) {
     return (size_t)kWavesPerBlock * tile_stack_lds_entries(max_depth) * kStackFields * 64 * sizeof(double);
 }
+// Queue launches that use the anchor grids and produce only the image let the idle lanes of a wave
+// take pending rays off the stacks of the busy ones (share_rays() in whitted_exact.inc.h).  The
+// wave then needs a place where several lanes can add to one pixel's colour and a word per lane
+// to pair givers with takers: kShareDwords dwords of LDS per wave, behind the stack entries of
+// the block's waves.
+#ifndef RT_SHARE
+#define RT_SHARE 1
+#endif
+constexpr int kShareDwords = 256;  // 3 x 64 colour sums (float), 64 exchange words
+__host__ __device__ constexpr bool share_rays_in(int mask_words, bool count, bool grid) {
+    return RT_SHARE != 0 && mask_words == 0 && !count && grid;
+}
+inline size_t share_lds_bytes() { return (size_t)kWavesPerBlock * kShareDwords * sizeof(uint32_t); }
 // Deep-stack launches: grid size and workspace.  The workspace starts with a 256-byte
 // header whose first word is the tile queue; the waves' regions follow.
 constexpr int kDeepMaxBlocks = 1280;      // 256 CUs x 5 resident blocks of 4 waves

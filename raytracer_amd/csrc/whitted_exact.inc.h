@@ -1190,7 +1190,10 @@ struct TileQueue {
 // Give every lane without a pixel (`have` false) the next pixel of the queue, as long as
 // there are any; begin(x, k) starts a pixel's walk (and leaves `have` false for a pixel
 // outside the frame, whose lane then takes another).  Called by all lanes of the wave.
-template <typename Begin>
+// ONE_TILE: stop after the pixels of one tile have been dealt out (lanes whose pixel lies outside
+// the frame stay without one), so that which pixels share a wave never depends on the order in
+// which the waves of the launch reach the queue.
+template <bool ONE_TILE = false, typename Begin>
 __device__ __forceinline__ void take_pixels(TileQueue& f, CArgs*& ap, bool& have, Begin& begin) {
     const int me = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     // New pixels are taken in batches of at least kRefillMin (lanes that start together stay
@@ -1237,6 +1240,7 @@ __device__ __forceinline__ void take_pixels(TileQueue& f, CArgs*& ap, bool& have
             begin(f.tx * kTile + (l & 7), f.ty * kTile + (l >> 3));
         }
         f.pos += m;
+        if (ONE_TILE && __builtin_amdgcn_ballot_w64(have) != 0ull) break;
     }
 }
 
@@ -1614,9 +1618,11 @@ __device__ __forceinline__ void trace_tile(AT& a, const int x, const int k, bool
     double bottom[kStackFields];  // (not used by this layout)
 #define RT_WALK_FINISHED have = false
 #define RT_STACK_IN_LDS true
+#define RT_STACK_LOW 0
     while (have) {
 #include "whitted_walk_step.inc.h"
     }
+#undef RT_STACK_LOW
 #undef RT_STACK_IN_LDS
 #undef RT_WALK_FINISHED
 
@@ -1625,9 +1631,99 @@ __device__ __forceinline__ void trace_tile(AT& a, const int x, const int k, bool
 }
 
 // One wave of a launch with a fixed grid: pixels from the tile queue until it is empty.
+// ---- rays shared between the lanes of a wave ---------------------------------------------------
+// The ray trees of a tile's pixels differ in size, and a wave walks until its longest one is
+// done: in a deep frame most lanes end up waiting.  Where only the image is asked for nothing but
+// the colour sum ties a ray to its pixel, so a lane without a ray is given the pending ray at the
+// BOTTOM of a busy lane's stack (the child of the shallowest node that still waits there: the
+// largest piece of work that lane can hand over), walks that subtree on its own stack and adds
+// what it collects to the pixel the ray came from.  The pixel's colour is then a sum in another
+// order (single precision, decides nothing); every ray is still traced exactly once with the same
+// doubles.  A stack therefore has a low end as well: entries lo .. sp-1 are pending.
+// `share` (kShareDwords dwords of LDS per wave): three rows of 64 colour sums, one per pixel of
+// the wave, and 64 exchange words.
+__device__ __forceinline__ void lds_add(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+// Pair the lanes without a ray with lanes that have a pending entry, in lane order.  The taker
+// announces itself in the exchange word of its rank, the giver writes its lowest entry - with the
+// lane that owns the pixel in bits 16.. of the node field - into the taker's first LDS slot (free:
+// the taker's stack is empty) and the taker continues with it.  Called by all lanes of the wave.
+template <bool DEEP>
+__device__ __forceinline__ void share_rays(bool& have, V3& o, V3& d, float& w, uint32_t& node, int& sp, int& lo, int& owner,
+                                           const double (&bottom)[kStackFields], const double* last_entry, double* stk,
+                                           const double* gstk, uint32_t* xchg, const int lane) {
+    const bool can_give = have && sp > lo;
+    const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
+    const unsigned long long givers = __builtin_amdgcn_ballot_w64(can_give);
+    if (idle == 0ull || givers == 0ull) return;
+    const int n_idle = __builtin_popcountll(idle), n_give = __builtin_popcountll(givers);
+    const int n = n_idle < n_give ? n_idle : n_give;
+    const int irank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+    const int grank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(givers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)givers, 0u));
+    const bool take = !have && irank < n;
+    if (take) xchg[irank] = (uint32_t)lane;
+    __builtin_amdgcn_wave_barrier();
+    if (can_give && grank < n) {
+        const int to = (int)xchg[grank];
+        double ent[kStackFields];
+        if (DEEP) {
+            if (lo < kStackRegEntries) {
+#pragma unroll
+                for (int f = 0; f < kStackFields; ++f) ent[f] = bottom[f];
+            } else if (lo < kStackRegEntries + kStackLdsEntries) {
+                const double* e = stk + (size_t)(lo - kStackRegEntries) * kStackFields * 64;
+#pragma unroll
+                for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
+            } else {
+                const double* e = gstk + (size_t)(lo - kStackRegEntries - kStackLdsEntries) * kStackFields * 64 + lane;
+#pragma unroll
+                for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
+            }
+        } else {
+            if (lo < kStackLdsEntries) {
+                const double* e = stk + (size_t)lo * kStackFields * 64;
+#pragma unroll
+                for (int f = 0; f < kStackFields; ++f) ent[f] = e[f * 64];
+            } else {
+#pragma unroll
+                for (int f = 0; f < kStackFields; ++f) ent[f] = last_entry[f];
+            }
+        }
+        ent[6] = __hiloint2double(__double2hiint(ent[6]) | (owner << 16), __double2loint(ent[6]));
+        double* e = stk - lane + to;
+#pragma unroll
+        for (int f = 0; f < kStackFields; ++f) e[f * 64] = ent[f];
+        ++lo;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (take) {
+        double ent[kStackFields];
+#pragma unroll
+        for (int f = 0; f < kStackFields; ++f) ent[f] = stk[f * 64];
+        o = mk(ent[0], ent[1], ent[2]);
+        d = mk(ent[3], ent[4], ent[5]);
+        w = __int_as_float(__double2loint(ent[6]));
+        const uint32_t tag = (uint32_t)__double2hiint(ent[6]);
+        node = tag & 0xffffu;
+        owner = (int)(tag >> 16);
+        sp = 0;
+        lo = 0;
+        have = true;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, bool GRID>
-__device__ __forceinline__ void trace_queue(TileQueue& feed, double* stk, double* gstk, const int lane,
+__device__ __forceinline__ void trace_queue(TileQueue& feed, double* stk, double* gstk, float* share, const int lane,
                                             uint32_t (&cnt)[kCounters]) {
+    constexpr bool SHARE = share_rays_in(MW, COUNT, GRID);
+    // SHARE: the lane's pixel is stored when the whole wave has run out of rays (`pixel` = this
+    // lane holds one that is not stored yet), and a lane's colour goes to the pixel of `owner`
+    bool pixel = false;
+    int owner = lane;
+    int lo = 0;  // SHARE: entries lo .. sp-1 of the stack are pending
+    uint32_t* xchg = (uint32_t*)(share + 3 * 64);
     CArgs* ap = feed.renders + feed.cur;
     int x = 0, k = 0;
     bool have = false;
@@ -1669,14 +1765,37 @@ __device__ __forceinline__ void trace_queue(TileQueue& feed, double* stk, double
 
 #define RT_WALK_FINISHED                                                     \
     do {                                                                     \
-        store_pixel<MW>(a, x, k, cr, cg, cb, first_hit, hmask, smask);      \
+        if (SHARE) {                                                         \
+            lds_add(share + owner, cr);                                      \
+            lds_add(share + 64 + owner, cg);                                 \
+            lds_add(share + 128 + owner, cb);                                \
+            cr = 0.0f; cg = 0.0f; cb = 0.0f;                                 \
+            sp = 0; lo = 0;                                                  \
+        } else {                                                             \
+            store_pixel<MW>(a, x, k, cr, cg, cb, first_hit, hmask, smask);  \
+        }                                                                    \
         have = false;                                                        \
     } while (0)
 #define RT_STACK_IN_LDS (!DEEP)
+#define RT_STACK_LOW (SHARE ? lo : 0)
     for (;;) {
         RT_MARK("refill");
-        take_pixels(feed, ap, have, begin_pixel);
-        if (!__any(have)) break;
+        if (SHARE) {
+            if (!__any(have)) {
+                // the wave has run out of rays: its pixels are complete
+                if (pixel) store_pixel<MW>(*ap, x, k, share[lane], share[64 + lane], share[128 + lane], first_hit, hmask, smask);
+                share[lane] = 0.0f; share[64 + lane] = 0.0f; share[128 + lane] = 0.0f;
+                take_pixels<true>(feed, ap, have, begin_pixel);
+                pixel = have;
+                owner = lane;
+                if (!__any(have)) break;
+            } else {
+                share_rays<DEEP>(have, o, d, w, node, sp, lo, owner, bottom, last_entry, stk, gstk, xchg, lane);
+            }
+        } else {
+            take_pixels(feed, ap, have, begin_pixel);
+            if (!__any(have)) break;
+        }
         if (have) {
             CArgs& a = *ap;
             const cdata_t geom = (cdata_t)(const double*)a.geom;
@@ -1687,6 +1806,7 @@ __device__ __forceinline__ void trace_queue(TileQueue& feed, double* stk, double
 #include "whitted_walk_step.inc.h"
         }
     }
+#undef RT_STACK_LOW
 #undef RT_STACK_IN_LDS
 #undef RT_WALK_FINISHED
     // The last wave of the launch to finish puts the queue back to zero for the next launch

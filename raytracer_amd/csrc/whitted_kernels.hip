@@ -58,13 +58,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     uint32_t cnt[kCounters] = {0};
     if (DEEP || TREE) {
         double* gstk = DEEP ? wave_gstack(a, (size_t)blockIdx.x * kWavesPerBlock + wave) : nullptr;
+        // (launches that share rays between lanes: the wave's colour sums and exchange words)
+        const int entries = DEEP ? stack_lds_entries(a.max_depth) : tile_stack_lds_entries(a.max_depth);
+        float* share = (float*)(lds_stack + (size_t)kWavesPerBlock * entries * kStackFields * 64) + wave * kShareDwords;
         TileQueue feed;
         feed.renders = (CArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // the one argument, where it lies
         feed.tile_end = nullptr;
         feed.queue = a.tile_queue;
         feed.n_tiles = a.tiles_x * a.tiles_y;
         feed.n_waves = (int)gridDim.x * kWavesPerBlock;
-        trace_queue<MW, COUNT, TREE, DEEP, LATE, GRID>(feed, stk, gstk, lane, cnt);
+        trace_queue<MW, COUNT, TREE, DEEP, LATE, GRID>(feed, stk, gstk, share, lane, cnt);
     } else {
         const int tx = blockIdx.x * kWavesPerBlock + wave;  // a block = 4 tiles side by side
         int ty = blockIdx.y;
@@ -117,7 +120,8 @@ template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, bool GRID>
 static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t stream, const SkyTable& sky) {
     const int bx = (a.tiles_x + kWavesPerBlock - 1) / kWavesPerBlock;
     if (bx <= 0 || a.tiles_y <= 0) return hipSuccess;
-    const size_t lds = DEEP ? stack_lds_bytes(a.max_depth) : tile_stack_lds_bytes(a.max_depth);
+    size_t lds = DEEP ? stack_lds_bytes(a.max_depth) : tile_stack_lds_bytes(a.max_depth);
+    if ((DEEP || TREE) && share_rays_in(MW, COUNT, GRID)) lds += share_lds_bytes();
     if (DEEP || TREE) {
         if (deep_blocks < 1 || deep_blocks > (DEEP ? kDeepMaxBlocks : kQueueMaxBlocks) || !a.tile_queue || (DEEP && !a.gstack)) return hipErrorInvalidValue;
         hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE, GRID>), dim3(deep_blocks), dim3(64 * kWavesPerBlock), lds, stream, a, sky);
@@ -145,13 +149,15 @@ void whitted_batch_kernel(KBatch, int n) {
         for (int i = 0; i < n; ++i) depth = max(depth, b.a[i].max_depth);
         double* stk = lds_stack + (size_t)wave * (DEEP ? stack_lds_entries(depth) : tile_stack_lds_entries(depth)) * kStackFields * 64 + lane;
         double* gstk = DEEP ? wave_gstack(b.a[0], (size_t)blockIdx.x * kWavesPerBlock + wave) : nullptr;
+        const int entries = DEEP ? stack_lds_entries(depth) : tile_stack_lds_entries(depth);
+        float* share = (float*)(lds_stack + (size_t)kWavesPerBlock * entries * kStackFields * 64) + wave * kShareDwords;
         TileQueue feed;
         feed.renders = b.a;
         feed.tile_end = b.tile_end;
         feed.queue = b.a[0].tile_queue;
         feed.n_tiles = b.tile_end[n - 1];
         feed.n_waves = (int)gridDim.x * kWavesPerBlock;
-        trace_queue<0, false, TREE, DEEP, LATE, GRID>(feed, stk, gstk, lane, cnt);
+        trace_queue<0, false, TREE, DEEP, LATE, GRID>(feed, stk, gstk, share, lane, cnt);
     } else {
         CArgs& a = b.a[blockIdx.z];
         if ((int)blockIdx.y >= a.tiles_y || (int)(blockIdx.x * kWavesPerBlock) >= a.tiles_x) return;
@@ -194,7 +200,8 @@ hipError_t launch_whitted_batch(const KBatch& b, int n, bool tree, bool grid, in
     if (n <= 0 || bx <= 0 || by <= 0) return hipSuccess;
     const bool deep = stack_global_entries(depth) > 0;
     const bool queue = deep || tree;
-    const size_t lds = deep ? stack_lds_bytes(depth) : tile_stack_lds_bytes(depth);
+    size_t lds = deep ? stack_lds_bytes(depth) : tile_stack_lds_bytes(depth);
+    if (queue && share_rays_in(0, false, grid)) lds += share_lds_bytes();
     if (queue && (deep_blocks < 1 || deep_blocks > (deep ? kDeepMaxBlocks : kQueueMaxBlocks) || !b.a[0].tile_queue || (deep && !b.a[0].gstack)))
         return hipErrorInvalidValue;
     const dim3 g = queue ? dim3(deep_blocks) : dim3(bx, by, n);

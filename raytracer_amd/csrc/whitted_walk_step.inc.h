@@ -187,7 +187,7 @@
 
         RT_MARK("pop");
         if (!next_in_regs) {
-            if (sp > 0) {
+            if (sp > RT_STACK_LOW) {  // (launches that share rays hand entries out from the low end)
                 --sp;
                 double ent[kStackFields];
                 if (RT_STACK_IN_LDS) {

@@ -383,10 +383,15 @@ def test_rt_render_in_parts_and_into_page_locked_memory(tracer):
         hf.close()
     # a depth-8 frame in parts: every part's launch re-arms the tile queue of the workspace
     tracer.upload_scene(*scenes.glass_scene())
+    # (an image-only launch of this scene lets the lanes of a wave share rays, which sums a
+    # pixel's colour in another order than the launch that also writes ids: colour tolerance)
     p = abi.make_params(1280, 720, 8)
-    assert np.array_equal(tracer.render(p, want_ids=False, want_masks=False)["bgr"], tracer.render(p)["bgr"])
+    whole = tracer.render(p)["bgr"]
+    first = tracer.render(p, want_ids=False, want_masks=False)["bgr"]
+    assert_parity({"bgr": first}, {"bgr": whole}, "glass depth 8 in parts")
     tracer.trim()
-    assert np.array_equal(tracer.render(p, want_ids=False, want_masks=False)["bgr"], tracer.render(p)["bgr"])
+    again = tracer.render(p, want_ids=False, want_masks=False)["bgr"]
+    assert np.array_equal(again, first)  # a new workspace, the same bytes
 
 
 @pytest.mark.parametrize("n_ctx,band_rows,size", [(1, 8, (640, 203)), (3, 8, (1920, 1083)), (8, 8, (3840, 2160)),
