@@ -55,7 +55,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t = DeviceTracer(0)
     t0 = time.time()
-    done = pixels = off_by_one = front_moved = 0
+    done = pixels = off_by_one = front_moved = shared_moved = 0
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed)
         prims, lights = random_scene(rng)
@@ -82,7 +82,16 @@ def main():
                 q = p.copy()
                 q["flags"] = mode | prune | abi.RT_FLAG_NOFRONT
                 img = t.render(q, want_ids=False, want_masks=False)
-                assert np.array_equal(img["bgr"], dev["bgr"]), f"seed {seed}: image-only kernel differs"
+                if mode & abi.RT_FLAG_GRID:
+                    # (queue launches with the grids let the lanes of a wave share rays: a pixel's
+                    # colour is then summed in another order)
+                    delta = np.abs(img["bgr"].astype(int) - dev["bgr"].astype(int)).max(axis=-1)
+                    assert delta.max(initial=0) <= 1, f"{what}: walked image-only render off by {delta.max()}"
+                    moved = int(np.count_nonzero(delta))
+                    shared_moved += moved
+                    assert moved <= max(10, w * h // 1000), f"{what}: walked image-only render differs in {moved} pixels"
+                else:
+                    assert np.array_equal(img["bgr"], dev["bgr"]), f"seed {seed}: image-only kernel differs"
                 # as callers get it: pixels ending at the primary ray finished in single precision
                 img = t.render(p, want_ids=False, want_masks=False)
                 delta = np.abs(img["bgr"].astype(int) - dev["bgr"].astype(int)).max(axis=-1)
@@ -97,7 +106,8 @@ def main():
             print(f"{done} scenes, {pixels} pixels, {time.time() - t0:.0f} s, next seed {seed}", flush=True)
     print(f"soak ok: {done} scenes, {pixels} pixels x 8 renders (4 object-loop modes, full and pruned ray tree), seeds up to {seed - 1}; small frames below 99.9 % "
           f"identical pixels held {off_by_one} pixels off by one; "
-          f"the image-only renders differ from the walked frames in {front_moved} pixels (by one)")
+          f"the image-only renders differ from the walked frames in {front_moved} pixels (by one); "
+          f"walked image-only renders of the grid modes (rays shared between lanes) in {shared_moved} pixels (by one)")
 
 
 if __name__ == "__main__":
