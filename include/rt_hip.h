@@ -225,7 +225,11 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims,
  *              Every hit, miss and spawn decision is the reference's; the colour
  *              arithmetic (which decides nothing) runs in single precision where the
  *              reference's runs in double: a channel is within 1 of the reference's
- *              byte, and equal to it on more than 99.9 % of the pixels of a frame
+ *              byte, and equal to it on more than 99.9 % of the pixels of a frame.
+ *              The same scene, camera and partition always give the same bytes; a
+ *              render that asks only for `bgr` may differ from one that also asks for
+ *              ids, masks or counters by 1 in a channel of a few pixels in a million
+ *              (it adds a pixel's colour terms up in another order)
  *   hit_id     rows*width int32: index of the object the primary ray hit
  *              (current_obj at src/main.cc:44, depth 1), -1 on a miss         nullable
  *   hit_mask   rows*width*rt_mask_words(max_depth) uint32. Nodes of the ray tree are
