@@ -1169,10 +1169,14 @@ constexpr int kRefillMin = RT_REFILL_MIN;
 // TileQueue (launches with a fixed grid): the launch's tiles - of one render, or of several
 // one after the other - are numbered 0..n_tiles-1 and handed out by an atomic counter, four
 // at a time (one at a time over the last quarter, which keeps the waves' finishing times
-// together).  A lane that has finished its pixel takes the next pixel of the wave's current
-// tile at once, so the lanes of a wave stay busy however different the ray trees of their
-// pixels are.  Pixels of two renders never share a wave: a tile of another render waits
-// until the lanes still walking have finished.
+// together).  A wave takes new pixels when at least kRefillMin of its lanes are without one;
+// kRefillMin is 64, i.e. a whole tile at a time once every lane has finished: lanes that start
+// together stay in step, and a step costs the union of the paths its lanes take, so mixing
+// pixels of different tiles and levels in a wave was measured to cost more than the idle
+// lanes do (RT_REFILL_MIN 32: glass 4K depth 8 18.8 -> 23.4 ms).  What keeps lanes busy
+// instead is share_rays() below (rays of the same tile handed from lane to lane).  Pixels of
+// two renders never share a wave: a tile of another render waits until the lanes still
+// walking have finished.
 struct TileQueue {
     CArgs* renders;
     const RT_CONST int32_t* tile_end;   // running totals of the renders' tiles; null = one render
@@ -1630,7 +1634,6 @@ __device__ __forceinline__ void trace_tile(AT& a, const int x, const int k, bool
     if (inside) store_pixel<MW>(a, x, k, cr, cg, cb, first_hit, hmask, smask);
 }
 
-// One wave of a launch with a fixed grid: pixels from the tile queue until it is empty.
 // ---- rays shared between the lanes of a wave ---------------------------------------------------
 // The ray trees of a tile's pixels differ in size, and a wave walks until its longest one is
 // done: in a deep frame most lanes end up waiting.  Where only the image is asked for nothing but
@@ -1714,6 +1717,7 @@ __device__ __forceinline__ void share_rays(bool& have, V3& o, V3& d, float& w, u
     __builtin_amdgcn_wave_barrier();
 }
 
+// One wave of a launch with a fixed grid: pixels from the tile queue until it is empty.
 template <int MW, bool COUNT, bool TREE, bool DEEP, bool LATE, bool GRID>
 __device__ __forceinline__ void trace_queue(TileQueue& feed, double* stk, double* gstk, float* share, const int lane,
                                             uint32_t (&cnt)[kCounters]) {
