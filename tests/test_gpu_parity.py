@@ -5,9 +5,28 @@ import pytest
 
 from raytracer_amd import abi, scenes
 from tests import oracle_lib
+from raytracer_amd.strips import rank_params as strips_params
 from tests.parity import assert_parity
 
 pytestmark = pytest.mark.gpu
+
+
+def _shares_rays(prims, params):
+    """Whether the image-only launch of this render hands rays from lane to lane inside a wave
+    (queue launches that use the anchor grids): a pixel's colour is then the same terms added
+    up in another order, and a channel may differ by one from the launch that also writes ids."""
+    flags = int(params["flags"])
+    spheres = len(prims) - int((prims["type"] == abi.RT_PRIM_PLANE).sum())
+    grid = (spheres >= 8 or flags & abi.RT_FLAG_GRID) and not flags & abi.RT_FLAG_NOGRID and spheres > 0
+    tree = (spheres >= 40 or flags & abi.RT_FLAG_TREE) and not flags & abi.RT_FLAG_LINEAR
+    return bool(grid and (tree or int(params["max_depth"]) > 5))
+
+
+def _assert_same_image(got, want, shares, what):
+    if shares:
+        assert_parity({"bgr": got}, {"bgr": want}, what)
+    else:
+        assert np.array_equal(got, want), what
 
 
 def _both(tracer, prims, lights, params, counters=True):
@@ -22,7 +41,7 @@ def _both(tracer, prims, lights, params, counters=True):
         walked = params.copy()
         walked["flags"] = int(params["flags"]) | abi.RT_FLAG_NOFRONT
         image_only = tracer.render(walked, want_ids=False, want_masks=False)
-        assert np.array_equal(image_only["bgr"], dev["bgr"]), "image-only kernel differs"
+        _assert_same_image(image_only["bgr"], dev["bgr"], _shares_rays(prims, params), "image-only kernel differs")
     ora = oracle_lib.render(prims, lights, params, want_counters=counters)
     if counters:
         # the image-only render as callers get it: pixels that end at the primary ray are
@@ -130,7 +149,12 @@ def test_glass_4k_depth8_rows(tracer):
     tracer.render_device(full, torch.cuda.current_stream().cuda_stream, out.data_ptr())
     torch.cuda.synchronize()
     rows = abi.strip_image_rows(p)
-    assert np.array_equal(out.cpu().numpy()[rows], dev["bgr"])
+    whole = out.cpu().numpy()
+    _assert_same_image(whole[rows], dev["bgr"], True, "rows of the whole image-only frame")
+    # the same call gives the same bytes (which pixels share a wave does not depend on timing)
+    tracer.render_device(full, torch.cuda.current_stream().cuda_stream, out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), whole)
 
 
 def test_many_lights_saturated(tracer):
@@ -280,6 +304,33 @@ def test_pixels_ending_at_the_primary_ray(tracer, name):
         part = tracer.render(p, want_ids=False, want_masks=False)["bgr"]
         rows = abi.strip_image_rows(p)
         assert np.array_equal(part, whole[rows]), (name, band_rows, first, step)
+
+
+@pytest.mark.parametrize("name,size,depth", [("glass", (333, 207), 8), ("glass", (64, 25), 7), ("spheres1024", (203, 117), 5),
+                                             ("spheres1024", (150, 75), 8), ("spheres64", (101, 67), 6)])
+def test_lanes_sharing_rays(tracer, name, size, depth):
+    """Image-only queue launches that use the anchor grids hand pending rays from lane to lane
+    inside a wave: ragged frames (tiles with lanes outside the frame), whole and as strips,
+    against the checker; the same bytes on every call; within the colour tolerance of the launch
+    that also writes ids (which does not share)."""
+    prims, lights = {"glass": scenes.glass_scene, "spheres1024": scenes.random_spheres_scene,
+                     "spheres64": lambda: scenes.random_spheres_scene(64, 5, seed=77)}[name]()
+    w, h = size
+    p = abi.make_params(w, h, depth)
+    assert _shares_rays(prims, p)
+    tracer.upload_scene(prims, lights)
+    ora = oracle_lib.render(prims, lights, p, want_ids=False, want_masks=False)
+    img = tracer.render(p, want_ids=False, want_masks=False)["bgr"]
+    assert_parity({"bgr": img}, {"bgr": ora["bgr"]}, f"{name} {w}x{h} D{depth} image only")
+    for _ in range(3):
+        assert np.array_equal(tracer.render(p, want_ids=False, want_masks=False)["bgr"], img)
+    assert_parity({"bgr": img}, {"bgr": tracer.render(p)["bgr"]}, "against the launch with ids")
+    # three interleaved strips of 8-row bands put together (tiles of a strip are cut differently)
+    got = np.zeros_like(img)
+    for r in range(3):
+        sp = strips_params(p, r, 3)
+        got[abi.strip_image_rows(sp)] = tracer.render(sp, want_ids=False, want_masks=False)["bgr"]
+    assert_parity({"bgr": got}, {"bgr": ora["bgr"]}, f"{name} strips image only")
 
 
 def test_glass_depth8(tracer):
