@@ -239,6 +239,13 @@ int make_args(rt_ctx* ctx, const rt_params* p, rt::KArgs& a) {
     a.ltab_stride = ctx->ltab_stride;
     a.front = (p->flags & RT_FLAG_NOFRONT) ? nullptr : ctx->d_front;
     a.n_front = ctx->n_front;
+    {   // where the blocks of `front` lie (the layout rt_upload_scene wrote), in dwords
+        const int planes2 = (ctx->n_planes + 1) & ~1;
+        a.front_spheres = ctx->n_front > 0 ? ((ctx->n_front + 1) & ~1) : 2;
+        a.front_anchors = planes2 * rt::kFrontPlaneDwords;
+        a.front_stride = rt::kFrontAnchorDwords + a.front_spheres * 8;
+        a.front_camera = a.front_anchors + ctx->n_lights * a.front_stride + rt::kFrontAnchorDwords;
+    }
     a.scene_p1max = ctx->scene_p1max;
     a.n_prims = ctx->n_prims;
     a.n_lights = ctx->n_lights;

@@ -135,6 +135,10 @@ struct KArgs {
     int32_t row_order;         // launches with one wave per tile: block row b renders tile row
                                // (first + b) mod tiles_y, or (first - b) mod tiles_y when bit 30 is set;
                                // first = the low 16 bits (see tile_row_order() in sky_table.h)
+    int32_t front_anchors;     // layout of `front` in dwords, worked out once on the host (a wave
+    int32_t front_stride;      // would spend a dozen scalar instructions on it): where the
+    int32_t front_camera;      // lights' blocks start, their pitch, the camera's sphere records,
+    int32_t front_spheres;     // sphere records per anchor (n_front rounded up to even, at least 2)
     // ---- the rest
     int32_t max_depth;
     const DGeom* geom;
@@ -169,10 +173,11 @@ struct KArgs {
     int32_t prune;             // ids, masks and counters describe the walk without the children of
                                // weight zero (the image-only kernels always leave those out)
 };
-constexpr int kFrontArgDwords = 24;
+constexpr int kFrontArgDwords = 28;
 static_assert(offsetof(KArgs, front) == 0 && offsetof(KArgs, bgr) == 8 && offsetof(KArgs, pw) == 16 &&
                   offsetof(KArgs, n_planes) == 32 && offsetof(KArgs, band_magic) == 68 && offsetof(KArgs, bgr_c) == 80 &&
-                  offsetof(KArgs, row_order) == 92 && offsetof(KArgs, max_depth) == 4 * kFrontArgDwords,
+                  offsetof(KArgs, row_order) == 92 && offsetof(KArgs, front_anchors) == 96 &&
+                  offsetof(KArgs, max_depth) == 4 * kFrontArgDwords,
               "FrontArgs reads the head of KArgs by position");
 
 // Screen bounds of the scene for launches with one wave per tile (sky_table.h): tile row ty reads

@@ -1339,18 +1339,14 @@ __device__ __forceinline__ void store_pixel(AT& a, int x, int k, float cr, float
 // 1e-11 (|ip|_1 + |p0|_1).  |p0|_1 is taken from the plane's record:
 // herr = 1.01 U (|h| + |p0|_1).
 //
-// A wave of this pass is short (about 900 issue cycles for a floor tile of the default scene),
-// so it should not spend its time on scalar loads that wait for one another: left to itself the
-// compiler fetches every kernel argument and record where it is first used, twenty waits in a
-// row.  The pass fetches in three stages instead and holds the values in scalar registers from
-// there on (RT_HOLD): its arguments (the head of KArgs, FrontArgs) together with the tile's
-// screen bounds; the first plane and the camera's first two sphere records; per light its
-// position, colour and first two sphere records.  A scene with more planes or spheres adds a
-// load per further record.
-#define RT_HOLD1(a) "+s"(a)
-#define RT_HOLD4(w, o) RT_HOLD1(w[o]), RT_HOLD1(w[o + 1]), RT_HOLD1(w[o + 2]), RT_HOLD1(w[o + 3])
-#define RT_HOLD8(w, o) RT_HOLD4(w, o), RT_HOLD4(w, o + 4)
-
+// A wave of this pass is short, and what bounds a launch made of such waves is the scalar unit:
+// a CU issues one scalar instruction per cycle for its four SIMDs, as many as it issues vector
+// instructions, and this code - records in scalar registers, a branch around every test that
+// most lanes do not need - has more scalar instructions than vector ones.  So nothing here may
+// cost scalar instructions for form's sake: the offsets into the table come from the host
+// (KArgs::front_anchors ..), and the loads are left where the compiler puts them (pinning the
+// values of a load in registers of their own, to issue the loads in three groups, cost 74 copies
+// per wave: default 4K frame 0.0838 -> 0.0798 ms without them).
 // The head of KArgs (kFrontArgDwords dwords) in scalar registers.
 struct FrontArgs {
     uint32_t w[kFrontArgDwords];
@@ -1372,16 +1368,16 @@ struct FrontArgs {
     __device__ __forceinline__ int sky_unit_shift() const { return (int)w[19]; }
     __device__ __forceinline__ float bgr_c(int i) const { return __uint_as_float(w[20 + i]); }
     __device__ __forceinline__ uint32_t row_order() const { return w[23]; }
+    __device__ __forceinline__ int front_anchors() const { return (int)w[24]; }
+    __device__ __forceinline__ int front_stride() const { return (int)w[25]; }
+    __device__ __forceinline__ int front_camera() const { return (int)w[26]; }
+    __device__ __forceinline__ int front_spheres() const { return (int)w[27]; }
 };
-// Fetches the arguments at `kp` (a KArgs in the constant address space) and the word at `extra`
-// with loads that are issued together.
-__device__ __forceinline__ FrontArgs load_front_args(const RT_CONST uint32_t* kp, const RT_CONST uint32_t* extra, uint32_t& extra_word) {
+// The arguments at `kp` (a KArgs in the constant address space).
+__device__ __forceinline__ FrontArgs load_front_args(const RT_CONST uint32_t* kp) {
     FrontArgs f;
 #pragma unroll
     for (int i = 0; i < kFrontArgDwords; ++i) f.w[i] = kp[i];
-    uint32_t e = *extra;
-    __asm__ volatile("" : RT_HOLD8(f.w, 0), RT_HOLD8(f.w, 8), RT_HOLD8(f.w, 16), RT_HOLD1(e));
-    extra_word = e;
     return f;
 }
 
@@ -1472,16 +1468,15 @@ __device__ __forceinline__ bool primary_only_pixel(const FrontArgs& a, const int
     // the table: plane records (an even number of them), then per anchor - the lights, then the
     // camera - a header and the sphere records (an even number, padded with records that never hit)
     const cfdata_t planes = a.front();
-    const int n_planes = a.n_planes(), n_spheres = a.n_front();
-    const int planes2 = (n_planes + 1) & ~1, spheres2 = n_spheres > 0 ? ((n_spheres + 1) & ~1) : 2;
-    const cfdata_t anchors = planes + planes2 * kFrontPlaneDwords;
-    const int anchor_stride = kFrontAnchorDwords + spheres2 * 8;
-    const cfdata_t camera = anchors + (size_t)a.n_lights() * anchor_stride + kFrontAnchorDwords;
+    const int n_planes = a.n_planes();
+    const int spheres2 = a.front_spheres();
+    const cfdata_t anchors = planes + a.front_anchors();
+    const int anchor_stride = a.front_stride();
+    const cfdata_t camera = planes + a.front_camera();
     uint32_t p0[20], c0[4], c1[4];
     front_load(p0, planes);  // (a scene without planes: whatever lies there, not looked at)
     front_load(c0, camera);
     front_load(c1, camera + 8);
-    __asm__ volatile("" : RT_HOLD8(p0, 0), RT_HOLD8(p0, 8), RT_HOLD4(p0, 16), RT_HOLD4(c0, 0), RT_HOLD4(c1, 0));
 
     // src/main.cc:135-138, src/view_frustum.h:37-46: frame row of strip row k, pixel vector
     const int band = (a.band_rows() == 1) ? k : (int)__umulhi((uint32_t)k, a.band_magic());
@@ -1537,7 +1532,6 @@ __device__ __forceinline__ bool primary_only_pixel(const FrontArgs& a, const int
             front_load(lw, anchor);  // FrontAnchor: position (three doubles), colour
             front_load(e0, anchor + kFrontAnchorDwords);
             front_load(e1, anchor + kFrontAnchorDwords + 8);
-            __asm__ volatile("" : RT_HOLD8(lw, 0), RT_HOLD1(lw[8]), RT_HOLD8(e0, 0), RT_HOLD8(e1, 0));
             const V3 lpos = mk(__hiloint2double((int)lw[1], (int)lw[0]), __hiloint2double((int)lw[3], (int)lw[2]),
                                __hiloint2double((int)lw[5], (int)lw[4]));
             const F3 ci = f3(__uint_as_float(lw[6]), __uint_as_float(lw[7]), __uint_as_float(lw[8]));

@@ -71,29 +71,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     } else {
         const int tx = blockIdx.x * kWavesPerBlock + wave;  // a block = 4 tiles side by side
         int ty = blockIdx.y;
-        int x = tx * kTile + (lane & 7);
-        int k = ty * kTile + (lane >> 3);  // row in strip order
+        const int x = tx * kTile + (lane & 7);
+        int k;  // row in strip order
         bool have;
         if (MW == 0 && !COUNT) {
-            // a tile outside the screen bounds of the scene is background (src/main.cc:49-53)
+            // A launch of this kind is mostly short waves, and what bounds those is the scalar
+            // unit of the CU (one scalar instruction per cycle for four SIMDs): every scalar
+            // instruction in front of the walk is paid 129,600 times per 4K frame.  So the test
+            // that ends most waves comes first and reads two words: a tile outside the screen
+            // bounds of the scene is background (src/main.cc:49-53).
             const RT_CONST uint32_t* kp = (const RT_CONST uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
             const RT_CONST uint32_t* sky = (const RT_CONST uint32_t*)((const RT_CONST char*)kp + sizeof(KArgs));
             // (the table is indexed by the block row: the host has laid it out in launch order)
             const uint32_t row = min((uint32_t)blockIdx.y, (uint32_t)(kSkyRows - 1));
-            uint32_t word;
-            // (the arguments the rest of this branch needs, and the bounds, in one fetch)
-            const FrontArgs fa = load_front_args(kp, sky + (row >> 1), word);
+            const uint32_t rng = sky[row >> 1] >> ((row & 1u) << 4);
+            const FrontArgs fa = load_front_args(kp);
+            const uint32_t col = (uint32_t)tx >> fa.sky_unit_shift();
+            const bool outside = col < (rng & 0xffu) || col > ((rng >> 8) & 0xffu);
             // The rows of tiles are launched in the order the host chose: those that hold the long
             // ray trees first, so that the launch ends on short waves (KArgs::row_order)
             const uint32_t order = fa.row_order();
+            const int tiles_y = (fa.rows() + kTile - 1) >> 3;  // (= gridDim.y, without the fetch)
             ty = (order & 0x40000000u) ? (int)(order & 0xffffu) - ty : (int)(order & 0xffffu) + ty;
-            ty += (ty < 0) ? (int)gridDim.y : 0;
-            ty -= (ty >= (int)gridDim.y) ? (int)gridDim.y : 0;
+            ty += (ty < 0) ? tiles_y : 0;
+            ty -= (ty >= tiles_y) ? tiles_y : 0;
             k = ty * kTile + (lane >> 3);
-            const uint32_t rng = word >> ((row & 1u) << 4);
-            const uint32_t col = (uint32_t)tx >> fa.sky_unit_shift();
             have = (x < fa.width()) && (k < fa.rows());
-            if (col < (rng & 0xffu) || col > ((rng >> 8) & 0xffu)) {
+            if (outside) {
                 if (have) {
                     uint8_t* dst = fa.bgr() + 3 * ((size_t)k * fa.width() + x);
                     dst[0] = (uint8_t)to_u8(fa.bgr_c(2));
@@ -108,7 +112,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                 have = have & !primary_only_pixel(fa, x, k, have);
                 if (!__any(have)) return;
             }
+#ifdef RT_PASS_ONLY  // measurement builds: what the launch costs without the walk
+            return;
+#endif
         } else {
+            k = ty * kTile + (lane >> 3);
             have = (x < a.width) && (k < a.rows);
         }
         trace_tile<MW, COUNT, TREE, DEEP, LATE, GRID>(a, x, k, have, stk, nullptr, lane, cnt);
@@ -122,6 +130,11 @@ static hipError_t launch_ttdl(const KArgs& a, int deep_blocks, hipStream_t strea
     if (bx <= 0 || a.tiles_y <= 0) return hipSuccess;
     size_t lds = DEEP ? stack_lds_bytes(a.max_depth) : tile_stack_lds_bytes(a.max_depth);
     if ((DEEP || TREE) && share_rays_in(MW, COUNT, GRID)) lds += share_lds_bytes();
+#ifdef RT_PASS_ONLY
+#ifndef RT_PASS_KEEP_LDS
+    if (!DEEP && !TREE && MW == 0 && !COUNT) lds = 0;
+#endif
+#endif
     if (DEEP || TREE) {
         if (deep_blocks < 1 || deep_blocks > (DEEP ? kDeepMaxBlocks : kQueueMaxBlocks) || !a.tile_queue || (DEEP && !a.gstack)) return hipErrorInvalidValue;
         hipLaunchKernelGGL((whitted_kernel<MW, COUNT, TREE, DEEP, LATE, GRID>), dim3(deep_blocks), dim3(64 * kWavesPerBlock), lds, stream, a, sky);
@@ -172,9 +185,7 @@ void whitted_batch_kernel(KBatch, int n) {
         const int k = ty * kTile + (lane >> 3);
         bool have = (x < a.width) && (k < a.rows);
         if (!GRID && a.front != nullptr && a.n_front >= 0) {
-            const RT_CONST uint32_t* kp = (const RT_CONST uint32_t*)&a;
-            uint32_t unused;
-            const FrontArgs fa = load_front_args(kp, kp, unused);
+            const FrontArgs fa = load_front_args((const RT_CONST uint32_t*)&a);
             have = have & !primary_only_pixel(fa, x, k, have);
             if (!__any(have)) return;
         }
