@@ -126,16 +126,17 @@ inline int cell_of(double t, int res) {
 
 }  // namespace detail
 
-// Grid resolution for a scene: cells about as wide as the spheres look from afar (the square
-// root of 16 cells per sphere and face), at least 32, and no more than keeps the cell table of
-// all anchors within 1 MiB - the lanes of a wave read cells and lists of their own, and a table
-// that does not stay in the 4 MiB L2 of an XCD next to the lists turns into memory traffic
-// (1024 spheres, 9 anchors: 600 MB per 4K frame at 128 cells per edge, 26 MB at 64, for 1.7 %
-// of the frame time).
+// Grid resolution for a scene: 128 cells per sphere and face (the lists of a cell are walked by
+// every lane on its own, so short lists count for more than a small table: 24 large spheres seen
+// from 17 anchors take 17.5 ms per 4K depth-8 frame at 32 cells per edge, 17.0 at 56), at least
+// 32, at most 128, and no more than keeps the cell table of all anchors within 1.4 MiB - the
+// lanes of a wave read cells and lists of their own, and a table that does not stay in the
+// 4 MiB L2 of an XCD next to the lists turns into memory traffic (1024 spheres, 9 anchors:
+// 600 MB per 4K frame at 128 cells per edge, 26 MB at 64; 64 and 80 take the same time).
 inline int anchor_grid_resolution(size_t n_spheres, size_t n_anchors) {
     int res = 32;
-    while (res < 128 && static_cast<size_t>(res) * res < 16 * n_spheres) res += 8;
-    while (res > 32 && 3ull * res * res * sizeof(GridCell) * n_anchors > (1u << 20)) res -= 8;
+    while (res < 128 && static_cast<size_t>(res) * res < 128 * n_spheres) res += 8;
+    while (res > 32 && 3ull * res * res * sizeof(GridCell) * n_anchors > 1468006ull) res -= 8;
     return res;
 }
 
