@@ -198,8 +198,10 @@ int rt_trim(rt_ctx* ctx);
 
 /*
  * Page-locked host memory for frames (hipHostMalloc, usable with every device): rt_render
- * and rt_render_node copy into such a buffer at the full PCIe rate, into ordinary memory at
- * about a third of it.  Errors are reported by rt_last_error(NULL).  No counterpart in the
+ * and rt_render_node copy into such a buffer at the full PCIe rate by DMA.  (Into ordinary
+ * memory rt_render's image-only form stages the frame through a page-locked buffer of its own
+ * and a few copy threads, about 20 % slower than the direct copy; the other forms leave the
+ * staging to the HIP runtime, at about a third of the rate.)  Errors are reported by rt_last_error(NULL).  No counterpart in the
  * reference, whose Screen allocates its buffers with new[] (src/screen.h:24-33).
  */
 int rt_host_alloc(size_t bytes, void** out);
@@ -243,7 +245,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_prim* prims, int32_t n_prims,
  * The copies run at the full PCIe rate when the host buffers are page-locked
  * (rt_host_alloc, hipHostMalloc, hipHostRegister), at about a third of it otherwise.  With
  * only `bgr` asked for, the partition is rendered in up to 8 parts and each part is copied
- * while the next one is rendered.
+ * while the next one is rendered; when `bgr` is ordinary memory (neither allocated by nor
+ * registered with the HIP runtime) the parts go by DMA into a page-locked buffer of the
+ * context and from there into `bgr` with a few threads of the library (4K frame: 0.67 ms
+ * against 0.56 ms into page-locked memory and 1.7 ms with the runtime's own staging).
  */
 int rt_render(rt_ctx* ctx, const rt_params* p, uint8_t* bgr, int32_t* hit_id,
               uint32_t* hit_mask, uint32_t* spawn_mask, rt_counters* counters);
