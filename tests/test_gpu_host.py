@@ -394,6 +394,32 @@ def test_rt_render_in_parts_and_into_page_locked_memory(tracer):
     assert np.array_equal(again, first)  # a new workspace, the same bytes
 
 
+def test_rt_render_into_ordinary_memory_with_counters(tracer):
+    """rt_render of the image alone into ordinary (not page-locked) memory stages the copy in the
+    library (DMA into its own page-locked buffer, copy threads): frames of sizes that do not
+    divide into its chunks, whole and as a strip, with the event counters asked for as well,
+    equal the render into page-locked memory and the full render's counters."""
+    from raytracer_amd.device import HostFrame
+
+    prims, lights = scenes.default_scene()
+    tracer.upload_scene(prims, lights)
+    for p in (abi.make_params(1999, 1001, 4), strips.rank_params(abi.make_params(2560, 1441, 5), 1, 2),
+              abi.make_params(3840, 2160, 5)):
+        full = tracer.render(p, want_counters=True)
+        img = tracer.render(p, want_ids=False, want_masks=False, want_counters=True)  # a fresh numpy array
+        shape = img["bgr"].shape
+        assert shape[0] * shape[1] * 3 >= (2 << 20)  # large enough for the staged path
+        for k in full["counters"].dtype.names:
+            assert int(img["counters"][k]) == int(full["counters"][k]), k
+        assert np.array_equal(img["bgr"], full["bgr"])  # (the counting kernels walk every pixel)
+        hf = HostFrame(shape)
+        tracer.render_into(p, hf.array)
+        again = np.full(shape, 7, dtype=np.uint8)
+        tracer.render_into(p, again)
+        assert np.array_equal(again, hf.array)
+        hf.close()
+
+
 @pytest.mark.parametrize("n_ctx,band_rows,size", [(1, 8, (640, 203)), (3, 8, (1920, 1083)), (8, 8, (3840, 2160)),
                                                   (4, 16, (1000, 37)), (5, 8, (64, 20))])
 def test_render_node_equals_whole_frame(tracer, n_ctx, band_rows, size):
